@@ -1,0 +1,284 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT PATH.
+
+A plain-numpy restatement of the reference's light-field SR hot path (BasicLFSR fork at
+``/root/reference``), written in the *reference's own* formulation (NCHW tensors, macro-pixel layout,
+dilated convolutions, explicit rearranges) so that it is an independent check of the HIP path, which
+computes the same functions in a different (view-major, channel-last) formulation.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module -- as the checker / the timed CPU baseline, never as a fallback for the product.
+
+Pinned: every function here is checked against golden vectors produced by importing and running the
+reference itself in the build container (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``;
+``tests/test_oracle_vs_golden.py``).  The reference holds no tests or fixtures of its own for this path
+(SURVEY.md section 4).
+
+All arithmetic runs in ``dtype`` (float64 by default: a sharper checker than the reference's own
+fp32; pass ``np.float32`` to mirror the reference's precision, which is what the CPU baseline times).
+Each function cites the reference file:line it restates.
+"""
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------
+# a1-a7: integer-indexing primitives (bit-exact)
+# ----------------------------------------------------------------------------------------------
+
+
+def sai2macpi(x, A):
+    """``SAI2MacPI`` DistgSSR.py:145-155 (dup LF_InterNet.py:155-165).
+    out[b,c,y*A+u,x*A+v] = in[b,c,u*h+y,v*w+x]."""
+    B, C, Hh, Ww = x.shape
+    h, w = Hh // A, Ww // A
+    return np.ascontiguousarray(x.reshape(B, C, A, h, A, w).transpose(0, 1, 3, 2, 5, 4).reshape(B, C, h * A, w * A))
+
+
+def macpi2sai(x, A):
+    """``MacPI2SAI`` DistgSSR.py:134-142.  out[b,c,u*h+y,v*w+x] = in[b,c,y*A+u,x*A+v]."""
+    B, C, Hh, Ww = x.shape
+    h, w = Hh // A, Ww // A
+    return np.ascontiguousarray(x.reshape(B, C, h, A, w, A).transpose(0, 1, 3, 2, 5, 4).reshape(B, C, A * h, A * w))
+
+
+def pixel_shuffle(x, r):
+    """``nn.PixelShuffle(r)`` as used at DistgSSR.py:26,89; EPIT.py:46; LFT.py:54; LF_InterNet.py:51,114,132.
+    out[b,c,y*r+i,x*r+j] = in[b,c*r*r+i*r+j,y,x]."""
+    B, Crr, H, W = x.shape
+    C = Crr // (r * r)
+    return np.ascontiguousarray(x.reshape(B, C, r, r, H, W).transpose(0, 1, 4, 2, 5, 3).reshape(B, C, H * r, W * r))
+
+
+def pixel_shuffle1d(x, f):
+    """``PixelShuffle1D`` DistgSSR.py:114-131 (factor-major channels).  out[b,c,y,x*f+k] = in[b,k*C+c,y,x]."""
+    B, fC, H, W = x.shape
+    C = fC // f
+    return np.ascontiguousarray(x.reshape(B, f, C, H, W).transpose(0, 2, 3, 4, 1).reshape(B, C, H, W * f))
+
+
+def _sym(i, n):
+    """Index into a length-n axis under edge-including mirror extension of period 2n."""
+    i = np.mod(i, 2 * n)
+    return np.where(i < n, i, 2 * n - 1 - i)
+
+
+def image_extend(im, bdr):
+    """``ImageExtend`` utils/utils.py:137-149: the 3x3 flip mosaic cropped to
+    [h-bdr0 : 2h+bdr1, w-bdr2 : 2w+bdr3]."""
+    h, w = im.shape[-2:]
+    ys = _sym(np.arange(-bdr[0], h + bdr[1]), h)
+    xs = _sym(np.arange(-bdr[2], w + bdr[3]), w)
+    return np.ascontiguousarray(im[..., ys[:, None], xs[None, :]])
+
+
+def lf_divide(data, A, P, S):
+    """``LFdivide`` utils/utils.py:152-166.  data (A*h0, A*w0) -> (numU, numV, A*P, A*P)."""
+    h0, w0 = data.shape[0] // A, data.shape[1] // A
+    d = data.reshape(A, h0, A, w0).transpose(0, 2, 1, 3).reshape(A * A, 1, h0, w0)
+    bdr = (P - S) // 2
+    numU = (h0 + bdr * 2 - 1) // S
+    numV = (w0 + bdr * 2 - 1) // S
+    pad = image_extend(d, [bdr, bdr + S - 1, bdr, bdr + S - 1])[:, 0]          # (A*A, hp, wp)
+    out = np.empty((numU, numV, A, P, A, P), dtype=data.dtype)
+    for n1 in range(numU):                                                      # F.unfold(k=P, stride=S)
+        for n2 in range(numV):
+            blk = pad[:, n1 * S:n1 * S + P, n2 * S:n2 * S + P].reshape(A, A, P, P)
+            out[n1, n2] = blk.transpose(0, 2, 1, 3)
+    return out.reshape(numU, numV, A * P, A * P)
+
+
+def lf_integrate(sub, A, pz, stride, h, w):
+    """``LFintegrate`` utils/utils.py:169-178: centre-crop stride x stride of every patch, tile, crop."""
+    if sub.ndim == 4:
+        n1, n2 = sub.shape[:2]
+        sub = sub.reshape(n1, n2, A, pz, A, pz).transpose(0, 1, 2, 4, 3, 5)
+    n1, n2 = sub.shape[:2]
+    bdr = (pz - stride) // 2
+    o = sub[:, :, :, :, bdr:bdr + stride, bdr:bdr + stride]
+    o = o.transpose(2, 3, 0, 4, 1, 5).reshape(A, A, n1 * stride, n2 * stride)
+    return np.ascontiguousarray(o[:, :, :h, :w])
+
+
+# ----------------------------------------------------------------------------------------------
+# floating-point building blocks (stock PyTorch ops the reference calls)
+# ----------------------------------------------------------------------------------------------
+
+
+def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
+    """``nn.Conv2d`` forward (cross-correlation), NCHW.  Tap-by-tap GEMM accumulation."""
+    B, C, H, W = x.shape
+    O, Cw, kh, kw = w.shape
+    assert C == Cw
+    sh, sw = stride
+    ph, pw = padding
+    dh, dw = dilation
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    xp = np.zeros((B, C, H + 2 * ph, W + 2 * pw), dtype=x.dtype)
+    xp[:, :, ph:ph + H, pw:pw + W] = x
+    out = np.zeros((B, O, Ho * Wo), dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            sl = xp[:, :, i * dh:i * dh + sh * (Ho - 1) + 1:sh, j * dw:j * dw + sw * (Wo - 1) + 1:sw]
+            out += np.matmul(w[:, :, i, j], sl.reshape(B, C, Ho * Wo))
+    out = out.reshape(B, O, Ho, Wo)
+    if bias is not None:
+        out = out + bias.reshape(1, O, 1, 1)
+    return out
+
+
+def leaky_relu(x, slope):
+    return np.where(x >= 0, x, x * np.asarray(slope, dtype=x.dtype))
+
+
+def _lin_coords(n_in, scale, dtype):
+    """PyTorch area_pixel_compute_source_index, align_corners=False, scale_factor given."""
+    dst = np.arange(n_in * scale, dtype=np.float64)
+    return (dst + 0.5) / scale - 0.5
+
+
+def interp_bilinear(x, s):
+    """``F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False)`` (DistgSSR.py:30)."""
+    def axis(n):
+        src = np.maximum(_lin_coords(n, s, x.dtype), 0.0)
+        i0 = np.floor(src).astype(np.int64)
+        i0 = np.minimum(i0, n - 1)
+        i1 = np.minimum(i0 + 1, n - 1)
+        l1 = (src - i0).astype(x.dtype)
+        return i0, i1, (1 - l1).astype(x.dtype), l1
+    H, W = x.shape[-2:]
+    y0, y1, wy0, wy1 = axis(H)
+    x0, x1, wx0, wx1 = axis(W)
+    rows = x[..., y0, :] * wy0[:, None] + x[..., y1, :] * wy1[:, None]
+    return rows[..., :, x0] * wx0 + rows[..., :, x1] * wx1
+
+
+def interp_bicubic(x, s):
+    """``F.interpolate(..., mode='bicubic', align_corners=False)`` (EPIT.py:167, LFT.py:269): a=-0.75,
+    border indices clamped."""
+    a = -0.75
+
+    def cc1(t):
+        return ((a + 2) * t - (a + 3)) * t * t + 1
+
+    def cc2(t):
+        return ((a * t - 5 * a) * t + 8 * a) * t - 4 * a
+
+    def axis(n):
+        src = _lin_coords(n, s, x.dtype)
+        i0 = np.floor(src)
+        t = src - i0
+        i0 = i0.astype(np.int64)
+        idx = np.stack([np.clip(i0 + k, 0, n - 1) for k in (-1, 0, 1, 2)])
+        wts = np.stack([cc2(t + 1), cc1(t), cc1(1 - t), cc2(2 - t)]).astype(x.dtype)
+        return idx, wts
+    H, W = x.shape[-2:]
+    iy, wy = axis(H)
+    ix, wx = axis(W)
+    rows = sum(x[..., iy[k], :] * wy[k][:, None] for k in range(4))
+    return sum(rows[..., :, ix[k]] * wx[k] for k in range(4))
+
+
+def linear(x, w, b=None):
+    y = np.matmul(x, w.T)
+    return y if b is None else y + b
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * g + b
+
+
+def mha(q, k, v, in_proj_w, out_proj_w, nheads, mask=None):
+    """``nn.MultiheadAttention`` forward, (L,N,E) layout, no biases, additive float mask (L,L)."""
+    L, N, E = q.shape
+    hd = E // nheads
+    wq, wk, wv = in_proj_w[:E], in_proj_w[E:2 * E], in_proj_w[2 * E:]
+    Q = linear(q, wq).reshape(L, N * nheads, hd).transpose(1, 0, 2)
+    K = linear(k, wk).reshape(L, N * nheads, hd).transpose(1, 0, 2)
+    V = linear(v, wv).reshape(L, N * nheads, hd).transpose(1, 0, 2)
+    S = np.matmul(Q, K.transpose(0, 2, 1)) / np.sqrt(np.asarray(hd, dtype=q.dtype))
+    if mask is not None:
+        S = S + mask
+    S = S - S.max(-1, keepdims=True)
+    P = np.exp(S)
+    P = P / P.sum(-1, keepdims=True)
+    O = np.matmul(P, V).transpose(1, 0, 2).reshape(L, N, E)
+    return linear(O, out_proj_w)
+
+
+# ----------------------------------------------------------------------------------------------
+# DistgSSR (model/SR/DistgSSR.py)
+# ----------------------------------------------------------------------------------------------
+
+
+def _cast(sd, dtype):
+    return {k: np.asarray(v, dtype=dtype) for k, v in sd.items()}
+
+
+def distg_block(x, sd, pre, A, taps=None):
+    """``DisentgBlock.forward`` DistgSSR.py:104-111 on the MacPI tensor x (B,64,A*h,A*w)."""
+    d = (A, A)
+    spa = leaky_relu(conv2d(x, sd[pre + "SpaConv.0.weight"], dilation=d, padding=d), 0.1)
+    spa = leaky_relu(conv2d(spa, sd[pre + "SpaConv.2.weight"], dilation=d, padding=d), 0.1)
+    ang = leaky_relu(conv2d(x, sd[pre + "AngConv.0.weight"], stride=d), 0.1)
+    ang = leaky_relu(conv2d(ang, sd[pre + "AngConv.2.weight"]), 0.1)
+    ang = pixel_shuffle(ang, A)
+
+    def epi(t):
+        e = leaky_relu(conv2d(t, sd[pre + "EPIConv.0.weight"], stride=(1, A), padding=(0, A * (A - 1) // 2)), 0.1)
+        e = leaky_relu(conv2d(e, sd[pre + "EPIConv.2.weight"]), 0.1)
+        return pixel_shuffle1d(e, A)
+    epih = epi(x)
+    epiv_t = epi(np.ascontiguousarray(x.transpose(0, 1, 3, 2)))
+    epiv = epiv_t.transpose(0, 1, 3, 2)
+    buf = np.concatenate((spa, ang, epih, epiv), axis=1)
+    buf = leaky_relu(conv2d(buf, sd[pre + "fuse.0.weight"]), 0.1)
+    buf = conv2d(buf, sd[pre + "fuse.2.weight"], dilation=d, padding=d)
+    if taps is not None:
+        taps.update(spa=spa, ang=ang, epih=epih, epiv_t=epiv_t)
+    return buf + x
+
+
+def distgssr_forward(x, sd, A, s, dtype=np.float64, taps=None):
+    """``get_model.forward`` DistgSSR.py:29-36.  x (B,1,A*h,A*w) SAI mosaic -> (B,1,A*h*s,A*w*s)."""
+    sd = _cast(sd, dtype)
+    x = np.asarray(x, dtype=dtype)
+    d = (A, A)
+    x_up = interp_bilinear(x, s)
+    m = sai2macpi(x, A)
+    buf0 = conv2d(m, sd["init_conv.weight"], dilation=d, padding=d)
+    if taps is not None:
+        taps["init_conv"] = buf0
+    buf = buf0
+    n_group = 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("disentg.Group."))
+    for g in range(n_group):
+        gin = buf
+        n_block = 1 + max(int(k.split(".")[4]) for k in sd if k.startswith(f"disentg.Group.{g}.Block."))
+        for b in range(n_block):
+            t = {} if (taps is not None and g == 0 and b == 0) else None
+            buf = distg_block(buf, sd, f"disentg.Group.{g}.Block.{b}.", A, t)
+            if t is not None:
+                taps.update({"b0_" + k: v for k, v in t.items()})
+                taps["b0_out"] = buf
+        buf = conv2d(buf, sd[f"disentg.Group.{g}.conv.weight"], dilation=d, padding=d) + gin
+        if taps is not None and g == 0:
+            taps["g0_out"] = buf
+    buf = conv2d(buf, sd["disentg.conv.weight"], dilation=d, padding=d) + buf0
+    if taps is not None:
+        taps["disentg_out"] = buf
+    sai = macpi2sai(buf, A)
+    up = conv2d(sai, sd["upsample.0.weight"], sd["upsample.0.bias"])
+    up = pixel_shuffle(up, s)
+    up = conv2d(up, sd["upsample.2.weight"])
+    return up + x_up
+
+
+def l1_loss(sr, hr):
+    """``get_loss`` DistgSSR.py:158-166 (``nn.L1Loss`` mean)."""
+    return np.abs(sr - hr).mean()
+
+
+def psnr(a, b):
+    """10 log10(1 / MSE), data_range 1.0 (formula of utils/utils.py:109 as skimage computes it)."""
+    mse = np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)
+    return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)

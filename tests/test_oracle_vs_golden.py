@@ -1,0 +1,109 @@
+"""CPU: the numpy oracle against golden vectors produced by running the reference itself
+(tests/golden/make_golden.py).  Integer ops bit-exact; float ops to fp32 round-off."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import lfsr_oracle as O
+from tests.helpers import GOLDEN, model_case, psnr
+
+IDX = np.load(os.path.join(GOLDEN, "index_ops.npz"))
+META = json.load(open(os.path.join(GOLDEN, "index_ops.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("tag", ["s2m_a", "s2m_b"])
+def test_sai_macpi(tag):
+    m = META[tag]
+    x = np.arange(m["B"] * m["C"] * m["A"] * m["h"] * m["A"] * m["w"], dtype=np.int32).reshape(
+        m["B"], m["C"], m["A"] * m["h"], m["A"] * m["w"])
+    assert np.array_equal(O.sai2macpi(x, m["A"]), IDX[tag + "_sai2macpi"])
+    assert np.array_equal(O.macpi2sai(x, m["A"]), IDX[tag + "_macpi2sai"])
+    assert np.array_equal(O.macpi2sai(O.sai2macpi(x, m["A"]), m["A"]), x)
+
+
+@pytest.mark.parametrize("tag", ["ps_a", "ps_b", "ps_c"])
+def test_pixel_shuffle(tag):
+    m = META[tag]
+    x = np.arange(m["B"] * m["C"] * m["r"] ** 2 * m["h"] * m["w"], dtype=np.int32).reshape(
+        m["B"], m["C"] * m["r"] ** 2, m["h"], m["w"])
+    assert np.array_equal(O.pixel_shuffle(x, m["r"]), IDX[tag])
+
+
+@pytest.mark.parametrize("tag", ["ps1d_a", "ps1d_b"])
+def test_pixel_shuffle1d(tag):
+    m = META[tag]
+    x = np.arange(m["B"] * m["C"] * m["f"] * m["h"] * m["w"], dtype=np.int32).reshape(
+        m["B"], m["C"] * m["f"], m["h"], m["w"])
+    assert np.array_equal(O.pixel_shuffle1d(x, m["f"]), IDX[tag])
+
+
+def test_image_extend():
+    m = META["imext"]
+    x = np.arange(np.prod(m["shape"]), dtype=np.int32).reshape(m["shape"])
+    assert np.array_equal(O.image_extend(x, m["bdr"]), IDX["imext"])
+
+
+@pytest.mark.parametrize("key", sorted(META["lfdivide"].keys()))
+def test_lfdivide_integrate(key):
+    m = META["lfdivide"][key]
+    A, h0, w0, P, S = m["A"], m["h0"], m["w0"], m["P"], m["S"]
+    x = np.arange(A * h0 * A * w0, dtype=np.int32).reshape(A * h0, A * w0)
+    sub = O.lf_divide(x, A, P, S)
+    assert sub.shape[:2] == (m["numU"], m["numV"])
+    assert sha(sub) == m["divide_sha"]
+    if "div_" + key in IDX.files:
+        assert np.array_equal(sub, IDX["div_" + key])
+    # round trip at scale 1 (the reference's own free property)
+    back = O.lf_integrate(sub, A, P, S, h0, w0)
+    assert np.array_equal(back.transpose(0, 2, 1, 3).reshape(A * h0, A * w0), x)
+    # x4 integrate on a known ramp
+    s = 4
+    big = (np.arange(sub.size * s * s, dtype=np.int64) % 16777213).astype(np.int32).reshape(
+        sub.shape[0], sub.shape[1], sub.shape[2] * s, sub.shape[3] * s)
+    integ = O.lf_integrate(big, A, P * s, S * s, h0 * s, w0 * s)
+    assert list(integ.shape) == m["integrate_s4_shape"]
+    assert sha(integ) == m["integrate_s4_sha"]
+
+
+DISTG_TAPS = {"init_conv_0": "init_conv", "b0_spa_0": "b0_spa", "b0_ang_0": "b0_ang", "b0_epi_last_0": "b0_epih",
+              "b0_epi_last_1": "b0_epiv_t", "b0_out_0": "b0_out", "g0_out_0": "g0_out", "disentg_out_0": "disentg_out"}
+
+
+@pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
+def test_distgssr_small(tag):
+    case, sd, x, npz = model_case("DistgSSR", tag)
+    taps = {}
+    y = O.distgssr_forward(x, sd, case["A"], case["s"], taps=taps)
+    g = npz[tag + "_out"]
+    assert y.shape == g.shape
+    assert np.abs(y - g).max() < 2e-5
+    assert psnr(y, g) > 100.0
+    if tag == "a5h8s4":
+        for gk, ok in DISTG_TAPS.items():
+            ref = npz[f"{tag}_{gk}"]
+            assert np.abs(taps[ok] - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), gk
+
+
+def test_distgssr_fp32_mode():
+    case, sd, x, npz = model_case("DistgSSR", "a3h6w8s2")
+    y = O.distgssr_forward(x, sd, case["A"], case["s"], dtype=np.float32)
+    assert y.dtype == np.float32
+    assert np.abs(y - npz["a3h6w8s2_out"]).max() < 5e-5
+
+
+def test_interp_against_torch():
+    torch = pytest.importorskip("torch")
+    import torch.nn.functional as F
+    x = np.random.default_rng(0).random((2, 1, 7, 9))
+    for s in (2, 4):
+        tb = F.interpolate(torch.from_numpy(x), scale_factor=s, mode="bilinear", align_corners=False).numpy()
+        tc = F.interpolate(torch.from_numpy(x), scale_factor=s, mode="bicubic", align_corners=False).numpy()
+        assert np.abs(O.interp_bilinear(x, s) - tb).max() < 1e-12
+        assert np.abs(O.interp_bicubic(x, s) - tc).max() < 1e-12
