@@ -1,0 +1,152 @@
+/*
+ * lfsr_hip.h -- C ABI of liblfsr_hip.so: the MI355X (gfx950) light-field SR hot path.
+ *
+ * Drop-in boundary for the reference's arithmetic layer (stock PyTorch ops called from
+ * model/SR/{DistgSSR,EPIT,LFT,LF_InterNet}.py and utils/utils.py of the BasicLFSR fork).  Every entry
+ * point cites the reference interface it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all data pointers are DEVICE pointers borrowed from the caller
+ *     (never freed or retained past the call, except packed weights / workspaces the caller hands
+ *     to a model context and keeps alive itself);
+ *   - outputs are pre-allocated by the caller;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: 0 on success, LFSR_E_ARG (-1) for a bad argument, LFSR_E_WS (-2) for a too-small
+ *     workspace, -(1000 + hipError_t) for a HIP runtime failure.  No exceptions cross the ABI;
+ *   - re-entrant; no global state.
+ *
+ * Tensor layouts
+ *   NCHW "SAI mosaic"  (B,C,A*h,A*w)  element [b,c,u*h+y,v*w+x]      -- what the reference passes around
+ *   NCHW "MacPI"       (B,C,h*A,w*A)  element [b,c,y*A+u,x*A+v]      -- DistgSSR / LF_InterNet interior
+ *   VCL  "view-major channel-last" [B][A*A][h][w][C] fp32             -- this library's interior layout:
+ *        one pixel's C channels are contiguous (256 B for C=64), so spatial, angular and epipolar
+ *        gathers are all coalesced and SAI<->MacPI rearranges disappear from the network interior.
+ *        A VCL operand is described by (ptr, stride, choff): channel c of pixel p lives at
+ *        ptr[p*stride + choff + c] (lets a branch write straight into a slice of a concat buffer).
+ */
+#ifndef LFSR_HIP_H
+#define LFSR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFSR_OK 0
+#define LFSR_E_ARG (-1)
+#define LFSR_E_WS (-2)
+
+/* library / build identification: returns a static NUL-terminated string ("lfsr_hip gfx950 ...") */
+const char* lfsr_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a1-a7: integer-indexing primitives, bit-exact, reference NCHW layouts.  elem_bytes is 2 or 4.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* SAI2MacPI, model/SR/DistgSSR.py:145-155 (dup LF_InterNet.py:155-165).  in/out (B,C,A*h,A*w). */
+int lfsr_sai2macpi(const void* in, void* out, int B, int C, int A, int h, int w, int elem_bytes, void* stream);
+/* MacPI2SAI, model/SR/DistgSSR.py:134-142 (dup LF_InterNet.py:144-152). */
+int lfsr_macpi2sai(const void* in, void* out, int B, int C, int A, int h, int w, int elem_bytes, void* stream);
+/* nn.PixelShuffle(r) as called at DistgSSR.py:26,89; EPIT.py:46; LFT.py:54; LF_InterNet.py:51,114,132.
+ * in (B,C*r*r,H,W) -> out (B,C,H*r,W*r). */
+int lfsr_pixel_shuffle2d(const void* in, void* out, int B, int C, int r, int H, int W, int elem_bytes, void* stream);
+/* PixelShuffle1D, model/SR/DistgSSR.py:114-131 (factor-major).  in (B,f*C,H,W) -> out (B,C,H,W*f). */
+int lfsr_pixel_shuffle1d(const void* in, void* out, int B, int C, int f, int H, int W, int elem_bytes, void* stream);
+/* ImageExtend, utils/utils.py:137-149.  in (N,h,w) -> out (N,h+top+bottom,w+left+right), symmetric. */
+int lfsr_image_extend(const void* in, void* out, int N, int h, int w, int top, int bottom, int left, int right,
+                      int elem_bytes, void* stream);
+/* LFdivide, utils/utils.py:152-166.  in (A*h0,A*w0) -> out (numU,numV,A*P,A*P);
+ * numU=(h0+2*bdr-1)/S, numV=(w0+2*bdr-1)/S, bdr=(P-S)/2 (returned through num_u/num_v if non-NULL;
+ * with out == NULL only the counts are computed). */
+int lfsr_lf_divide(const void* in, void* out, int A, int h0, int w0, int P, int S, int elem_bytes,
+                   int* num_u, int* num_v, void* stream);
+/* LFintegrate, utils/utils.py:169-178.  in (numU,numV,A*pz,A*pz) -> out (A,A,h,w). */
+int lfsr_lf_integrate(const void* in, void* out, int A, int numU, int numV, int pz, int stride, int h, int w,
+                      int elem_bytes, void* stream);
+
+/* NCHW <-> VCL (fp32).  layout: 0 = SAI mosaic, 1 = MacPI.  VCL side described by (stride, choff). */
+int lfsr_nchw_to_vcl(const float* in, float* out, int out_stride, int out_choff, int B, int C, int A, int h, int w,
+                     int layout, void* stream);
+int lfsr_vcl_to_nchw(const float* in, int in_stride, int in_choff, float* out, int B, int C, int A, int h, int w,
+                     int layout, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * d1-d9: DistgSSR operator classes on VCL tensors (fp32, MFMA v_mfma_f32_32x32x2_f32 = exact fp32).
+ * Weights are passed PACKED (see lfsr_pack_*): [tap][Npad][Cin], k contiguous, Npad = N rounded up to 32.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Pack a PyTorch conv weight (O,C,kh,kw) (device, fp32) into [kh*kw][Npad][C].
+ * perm = 0: n' = n.   perm = 1 (PixelShuffle(A) feeding VCL views, DistgSSR.py:87-89): the reference's
+ * output channel c*r2 + q becomes n' = q*ch + c (r2 = O/ch views, ch channels per view). */
+int lfsr_pack_conv_weight(const float* w, float* packed, int O, int C, int taps, int perm, int ch, void* stream);
+size_t lfsr_packed_weight_floats(int O, int C, int taps);
+
+/* per-view 3x3 conv, zero pad 1 (== the MacPI conv "k3, dilation A, padding A" of DistgSSR.py:22,47,64,
+ * 79-83,101; == Conv3d(1,3,3) of EPIT.py:24-32,136-142 / LFT.py:36-46), Cin=Cout=64:
+ *   y = act(conv(x)) [+ r1] [+ r2],  act = LeakyReLU(slope) if slope != 1.0f.
+ * n_img = B*A*A images of h x w. */
+int lfsr_conv3x3_fwd(const float* x, int x_stride, int x_choff, const float* w_packed,
+                     float* y, int y_stride, int y_choff,
+                     const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                     int n_img, int h, int w, float slope, void* stream);
+
+/* pointwise (1x1) conv: y[p, choff + n] = act(sum_k x[p,k] * W[n,k] (+bias[n])), Cin in {16,32,64,144},
+ * any N (DistgSSR.py:99 fuse.0).  M pixels. */
+int lfsr_pointwise_fwd(const float* x, int x_stride, int x_choff, int cin, const float* w_packed, const float* bias,
+                       float* y, int y_stride, int y_choff, int M, int N, float slope, void* stream);
+
+/* AngConv, DistgSSR.py:84-90: t = lrelu(conv AxA stride A 64->16); y = lrelu(1x1 16->16*A*A) scattered
+ * by PixelShuffle(A) to the A*A views.  tmp: (B*h*w*16) floats. w1 packed perm 0, w2 packed perm 1 (ch 16). */
+int lfsr_angconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                     float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, float slope, void* stream);
+
+/* EPIConv, DistgSSR.py:91-97 (horizontal: vertical = 0) and its transposed application DistgSSR.py:108
+ * (vertical = 1, same weights): t = lrelu(conv 1xA^2 stride A pad A(A-1)/2 64->32);
+ * y = lrelu(1x1 32->32*A) scattered by PixelShuffle1D(A).  tmp: (B*A*h*w*32) floats. */
+int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                     float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical,
+                     float slope, void* stream);
+
+/* init_conv, DistgSSR.py:22,32 fused with SAI2MacPI (DistgSSR.py:31): x (B,1,A*h,A*w) SAI mosaic NCHW,
+ * w (64,1,3,3) raw PyTorch layout -> y VCL 64 channels. */
+int lfsr_initconv_fwd(const float* x, const float* w, float* y, int y_stride, int y_choff, int B, int A, int h, int wd,
+                      void* stream);
+
+/* upsample head, DistgSSR.py:24-27,35 fused with MacPI2SAI (:34), PixelShuffle(s) and the bilinear skip
+ * (:30): out (B,1,A*h*s,A*w*s) = PS_s(W'f + b') + bilinear_s(x_lr), with the linear chain
+ * 1x1(64->64 s^2, bias) -> PixelShuffle -> 1x1(64->1) folded to W' (s^2 x 64), b' (s^2) by lfsr_fold_head. */
+int lfsr_fold_head(const float* w0, const float* b0, const float* w2, float* wf, float* bf, int C, int s, void* stream);
+int lfsr_upsample_head_fwd(const float* f, int f_stride, int f_choff, const float* wf, const float* bf,
+                           const float* x_lr, float* out, int B, int A, int h, int w, int s, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-model driver: DistgSSR forward (get_model.forward, DistgSSR.py:29-36).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lfsr_distgssr lfsr_distgssr;
+
+int lfsr_distgssr_create(lfsr_distgssr** ctx, int A, int scale, int n_group, int n_block, int channels);
+void lfsr_distgssr_destroy(lfsr_distgssr* ctx);
+/* bytes of device memory the packed weights need; caller allocates and hands over with set_packed */
+size_t lfsr_distgssr_packed_bytes(const lfsr_distgssr* ctx);
+int lfsr_distgssr_set_packed(lfsr_distgssr* ctx, void* packed, size_t bytes);
+/* feed one state_dict entry (reference key names), raw PyTorch layout, device fp32.
+ * Returns LFSR_E_ARG for an unknown key or a wrong element count. */
+int lfsr_distgssr_load_param(lfsr_distgssr* ctx, const char* key, const float* data, size_t numel, void* stream);
+/* after all params are loaded: folds the upsample head; returns LFSR_E_ARG if a parameter is missing */
+int lfsr_distgssr_finalize(lfsr_distgssr* ctx, void* stream);
+size_t lfsr_distgssr_workspace_bytes(const lfsr_distgssr* ctx, int B, int h, int w);
+/* x (B,1,A*h,A*w) -> out (B,1,A*h*s,A*w*s), both NCHW SAI mosaics, fp32 */
+int lfsr_distgssr_forward(lfsr_distgssr* ctx, const float* x, float* out, int B, int h, int w,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* parity variant: additionally writes interior activations as NCHW MacPI (B,64,h*A,w*A) tensors into
+ * taps[i] (device pointers, NULL = skip): 0 = init_conv output, 1 = block(0,0) output, 2 = group 0 output,
+ * 3 = disentg output; and block(0,0)'s concat buffer (B,144,h*A,w*A) into taps[4]. */
+int lfsr_distgssr_forward_taps(lfsr_distgssr* ctx, const float* x, float* out, int B, int h, int w,
+                               void* workspace, size_t workspace_bytes, float* const* taps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFSR_HIP_H */

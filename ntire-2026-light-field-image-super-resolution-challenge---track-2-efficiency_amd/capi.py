@@ -1,0 +1,352 @@
+"""ctypes binding of liblfsr_hip.so (the C ABI declared in include/lfsr_hip.h).
+
+This is the ONLY bridge between the Python host code and the HIP path.  There is no CPU fallback: if
+the shared library is missing, or a tensor is not a contiguous CUDA(ROCm) tensor, the call raises.
+PyTorch is used for device memory and streams only.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblfsr_hip.so")
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_f = C.c_float
+c_sz = C.c_size_t
+
+# name -> (restype, argtypes): mirrors include/lfsr_hip.h line by line
+SIGNATURES = {
+    "lfsr_version": (C.c_char_p, []),
+    "lfsr_sai2macpi": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_macpi2sai": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_pixel_shuffle2d": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_pixel_shuffle1d": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_image_extend": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_lf_divide": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), c_p]),
+    "lfsr_lf_integrate": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_nchw_to_vcl": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_vcl_to_nchw": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_pack_conv_weight": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_packed_weight_floats": (c_sz, [c_i, c_i, c_i]),
+    "lfsr_conv3x3_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_pointwise_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_angconv_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_epiconv_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_initconv_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_fold_head": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "lfsr_upsample_head_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_distgssr_create": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i, c_i]),
+    "lfsr_distgssr_destroy": (None, [c_p]),
+    "lfsr_distgssr_packed_bytes": (c_sz, [c_p]),
+    "lfsr_distgssr_set_packed": (c_i, [c_p, c_p, c_sz]),
+    "lfsr_distgssr_load_param": (c_i, [c_p, C.c_char_p, c_p, c_sz, c_p]),
+    "lfsr_distgssr_finalize": (c_i, [c_p, c_p]),
+    "lfsr_distgssr_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
+    "lfsr_distgssr_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "lfsr_distgssr_forward_taps": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, C.POINTER(c_p), c_p]),
+}
+
+_lib = None
+
+
+class LfsrError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the C-ABI library (no GPU needed) and bind every declared symbol; raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LfsrError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback for the HIP path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc == -1:
+            msg = "bad argument"
+        elif rc == -2:
+            msg = "workspace too small"
+        else:
+            msg = f"HIP error {-rc - 1000}"
+        raise LfsrError(f"{what}: {msg} (rc={rc})")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_ptr(t, what="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise LfsrError(f"{what} must be a CUDA/ROCm tensor: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise LfsrError(f"{what} must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _elem(t):
+    eb = t.element_size()
+    if eb not in (2, 4):
+        raise LfsrError(f"unsupported element size {eb}")
+    return eb
+
+
+# ---------------------------------------------------------------------------------------------------
+# a1-a7 on torch tensors
+# ---------------------------------------------------------------------------------------------------
+
+def sai2macpi(x, A):
+    """SAI2MacPI, DistgSSR.py:145-155."""
+    lib = load()
+    B, Cc, Hh, Ww = x.shape
+    out = torch.empty_like(x)
+    check(lib.lfsr_sai2macpi(dev_ptr(x), dev_ptr(out), B, Cc, A, Hh // A, Ww // A, _elem(x), stream_ptr()), "sai2macpi")
+    return out
+
+
+def macpi2sai(x, A):
+    """MacPI2SAI, DistgSSR.py:134-142."""
+    lib = load()
+    B, Cc, Hh, Ww = x.shape
+    out = torch.empty_like(x)
+    check(lib.lfsr_macpi2sai(dev_ptr(x), dev_ptr(out), B, Cc, A, Hh // A, Ww // A, _elem(x), stream_ptr()), "macpi2sai")
+    return out
+
+
+def pixel_shuffle2d(x, r):
+    lib = load()
+    B, Crr, H, W = x.shape
+    Cc = Crr // (r * r)
+    out = torch.empty((B, Cc, H * r, W * r), dtype=x.dtype, device=x.device)
+    check(lib.lfsr_pixel_shuffle2d(dev_ptr(x), dev_ptr(out), B, Cc, r, H, W, _elem(x), stream_ptr()), "pixel_shuffle2d")
+    return out
+
+
+def pixel_shuffle1d(x, f):
+    """PixelShuffle1D, DistgSSR.py:114-131."""
+    lib = load()
+    B, fC, H, W = x.shape
+    Cc = fC // f
+    out = torch.empty((B, Cc, H, W * f), dtype=x.dtype, device=x.device)
+    check(lib.lfsr_pixel_shuffle1d(dev_ptr(x), dev_ptr(out), B, Cc, f, H, W, _elem(x), stream_ptr()), "pixel_shuffle1d")
+    return out
+
+
+def image_extend(im, bdr):
+    """ImageExtend, utils/utils.py:137-149.  im (..., h, w), bdr = [top, bottom, left, right]."""
+    lib = load()
+    h, w = im.shape[-2:]
+    N = im.numel() // (h * w) if h * w else 0
+    out = torch.empty(tuple(im.shape[:-2]) + (h + bdr[0] + bdr[1], w + bdr[2] + bdr[3]), dtype=im.dtype, device=im.device)
+    check(lib.lfsr_image_extend(dev_ptr(im), dev_ptr(out), N, h, w, bdr[0], bdr[1], bdr[2], bdr[3], _elem(im), stream_ptr()), "image_extend")
+    return out
+
+
+def lf_divide(data, A, P, S):
+    """LFdivide, utils/utils.py:152-166.  data (A*h0, A*w0) -> (numU, numV, A*P, A*P)."""
+    lib = load()
+    if data.dim() != 2:
+        raise LfsrError("LFdivide expects a 2-D (A*h0, A*w0) mosaic")
+    h0, w0 = data.shape[0] // A, data.shape[1] // A
+    nu, nv = c_i(0), c_i(0)
+    check(lib.lfsr_lf_divide(None, None, A, h0, w0, P, S, _elem(data), C.byref(nu), C.byref(nv), None), "lf_divide(count)")
+    out = torch.empty((nu.value, nv.value, A * P, A * P), dtype=data.dtype, device=data.device)
+    check(lib.lfsr_lf_divide(dev_ptr(data), dev_ptr(out), A, h0, w0, P, S, _elem(data), None, None, stream_ptr()), "lf_divide")
+    return out
+
+
+def lf_integrate(sub, A, pz, stride, h, w):
+    """LFintegrate, utils/utils.py:169-178.  sub (numU,numV,A*pz,A*pz) [or 6-D n1 n2 a1 a2 h w] -> (A,A,h,w)."""
+    lib = load()
+    if sub.dim() == 6:   # the reference accepts the already-split form too (utils.py:170-172)
+        n1, n2 = sub.shape[:2]
+        sub = sub.permute(0, 1, 2, 4, 3, 5).reshape(n1, n2, A * pz, A * pz).contiguous()
+    n1, n2 = sub.shape[:2]
+    out = torch.empty((A, A, h, w), dtype=sub.dtype, device=sub.device)
+    check(lib.lfsr_lf_integrate(dev_ptr(sub), dev_ptr(out), A, n1, n2, pz, stride, h, w, _elem(sub), stream_ptr()), "lf_integrate")
+    return out
+
+
+def nchw_to_vcl(x, A, layout, out=None, choff=0):
+    """(B,C,A*h,A*w) NCHW [layout 0 = SAI mosaic, 1 = MacPI] -> VCL (B*A*A*h*w, stride) fp32."""
+    lib = load()
+    B, Cc, Hh, Ww = x.shape
+    h, w = Hh // A, Ww // A
+    if out is None:
+        out = torch.empty((B * A * A * h * w, Cc), dtype=torch.float32, device=x.device)
+    check(lib.lfsr_nchw_to_vcl(dev_ptr(x), dev_ptr(out), out.shape[1], choff, B, Cc, A, h, w, layout, stream_ptr()), "nchw_to_vcl")
+    return out
+
+
+def vcl_to_nchw(v, B, Cc, A, h, w, layout, choff=0):
+    lib = load()
+    out = torch.empty((B, Cc, A * h, A * w), dtype=torch.float32, device=v.device)
+    check(lib.lfsr_vcl_to_nchw(dev_ptr(v), v.shape[1], choff, dev_ptr(out), B, Cc, A, h, w, layout, stream_ptr()), "vcl_to_nchw")
+    return out
+
+
+def pack_conv_weight(w, perm=0, ch=0):
+    """(O,C,kh,kw) -> packed [kh*kw][Npad][C] (see include/lfsr_hip.h)."""
+    lib = load()
+    O, Cc = w.shape[:2]
+    taps = w.numel() // (O * Cc)
+    n = lib.lfsr_packed_weight_floats(O, Cc, taps)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.lfsr_pack_conv_weight(dev_ptr(w), dev_ptr(out), O, Cc, taps, perm, ch, stream_ptr()), "pack_conv_weight")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# DistgSSR whole-model runtime
+# ---------------------------------------------------------------------------------------------------
+
+class DistgSSRRuntime:
+    """Owns one lfsr_distgssr context + its packed weights and workspaces (torch allocations)."""
+
+    def __init__(self, A, scale, n_group=4, n_block=4, channels=64):
+        self.lib = load()
+        self.A, self.scale = A, scale
+        ctx = c_p()
+        check(self.lib.lfsr_distgssr_create(C.byref(ctx), A, scale, n_group, n_block, channels), "distgssr_create")
+        self.ctx = ctx
+        self.packed = None
+        self.ws = {}
+        self.loaded_version = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.lfsr_distgssr_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    def load_state(self, named_tensors, device):
+        """named_tensors: iterable of (key, fp32 CUDA tensor) with the reference's state_dict names."""
+        nbytes = self.lib.lfsr_distgssr_packed_bytes(self.ctx)
+        if self.packed is None or self.packed.device != device:
+            self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(self.lib.lfsr_distgssr_set_packed(self.ctx, dev_ptr(self.packed), nbytes), "distgssr_set_packed")
+        st = stream_ptr()
+        for k, t in named_tensors:
+            t = t.detach()
+            if t.dtype != torch.float32:
+                t = t.float()
+            t = t.contiguous()
+            check(self.lib.lfsr_distgssr_load_param(self.ctx, k.encode(), dev_ptr(t, k), t.numel(), st), f"distgssr_load_param({k})")
+        check(self.lib.lfsr_distgssr_finalize(self.ctx, st), "distgssr_finalize")
+
+    def _workspace(self, B, h, w, device):
+        key = (B, h, w, device)
+        if key not in self.ws:
+            self.ws.clear()   # one live workspace per runtime
+            n = self.lib.lfsr_distgssr_workspace_bytes(self.ctx, B, h, w)
+            self.ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
+        return self.ws[key]
+
+    def forward(self, x, taps=None):
+        """x (B,1,A*h,A*w) fp32 CUDA -> (B,1,A*h*s,A*w*s).  taps: optional list of 5 bools."""
+        B, c1, Hh, Ww = x.shape
+        if c1 != 1 or Hh % self.A or Ww % self.A:
+            raise LfsrError(f"bad input shape {tuple(x.shape)} for angRes {self.A}")
+        if x.dtype != torch.float32:
+            raise LfsrError("DistgSSR HIP path computes in fp32; got " + str(x.dtype))
+        h, w = Hh // self.A, Ww // self.A
+        x = x.contiguous()
+        out = torch.empty((B, 1, Hh * self.scale, Ww * self.scale), dtype=torch.float32, device=x.device)
+        ws = self._workspace(B, h, w, x.device)
+        if taps is None:
+            check(self.lib.lfsr_distgssr_forward(self.ctx, dev_ptr(x), dev_ptr(out), B, h, w, dev_ptr(ws), ws.numel(), stream_ptr()),
+                  "distgssr_forward")
+            return out
+        bufs = []
+        arr = (c_p * 5)()
+        for i in range(5):
+            if taps[i]:
+                t = torch.empty((B, 144 if i == 4 else 64, Hh, Ww), dtype=torch.float32, device=x.device)
+                arr[i] = t.data_ptr()
+            else:
+                t = None
+                arr[i] = None
+            bufs.append(t)
+        check(self.lib.lfsr_distgssr_forward_taps(self.ctx, dev_ptr(x), dev_ptr(out), B, h, w, dev_ptr(ws), ws.numel(), arr, stream_ptr()),
+              "distgssr_forward_taps")
+        return out, bufs
+
+
+# ---------------------------------------------------------------------------------------------------
+# d1-d9 operator-level wrappers on VCL tensors (2-D torch tensors: (pixels, stride))
+# ---------------------------------------------------------------------------------------------------
+
+def _opt(t):
+    return dev_ptr(t) if t is not None else None
+
+
+def conv3x3(x, w_packed, n_img, h, w, slope=1.0, res1=None, res2=None, out=None, out_choff=0, x_choff=0):
+    lib = load()
+    if out is None:
+        out = torch.empty((n_img * h * w, 64), dtype=torch.float32, device=x.device)
+    check(lib.lfsr_conv3x3_fwd(dev_ptr(x), x.shape[1], x_choff, dev_ptr(w_packed), dev_ptr(out), out.shape[1], out_choff,
+                               _opt(res1), res1.shape[1] if res1 is not None else 0, 0,
+                               _opt(res2), res2.shape[1] if res2 is not None else 0, 0,
+                               n_img, h, w, slope, stream_ptr()), "conv3x3_fwd")
+    return out
+
+
+def pointwise(x, cin, w_packed, N, slope=1.0, bias=None, out=None, out_choff=0, x_choff=0):
+    lib = load()
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(lib.lfsr_pointwise_fwd(dev_ptr(x), x.shape[1], x_choff, cin, dev_ptr(w_packed), _opt(bias), dev_ptr(out), out.shape[1], out_choff,
+                                 M, N, slope, stream_ptr()), "pointwise_fwd")
+    return out
+
+
+def angconv(x, w1p, w2p, B, A, h, w, slope, out, out_choff):
+    lib = load()
+    tmp = torch.empty((B * h * w, 16), dtype=torch.float32, device=x.device)
+    check(lib.lfsr_angconv_fwd(dev_ptr(x), x.shape[1], 0, dev_ptr(w1p), dev_ptr(w2p), dev_ptr(tmp), dev_ptr(out), out.shape[1], out_choff,
+                               B, A, h, w, slope, stream_ptr()), "angconv_fwd")
+    return out
+
+
+def epiconv(x, w1p, w2p, B, A, h, w, vertical, slope, out, out_choff):
+    lib = load()
+    tmp = torch.empty((B * A * h * w, 32), dtype=torch.float32, device=x.device)
+    check(lib.lfsr_epiconv_fwd(dev_ptr(x), x.shape[1], 0, dev_ptr(w1p), dev_ptr(w2p), dev_ptr(tmp), dev_ptr(out), out.shape[1], out_choff,
+                               B, A, h, w, int(vertical), slope, stream_ptr()), "epiconv_fwd")
+    return out
+
+
+def initconv(x, w, A):
+    lib = load()
+    B, _, Hh, Ww = x.shape
+    h, wd = Hh // A, Ww // A
+    out = torch.empty((B * A * A * h * wd, 64), dtype=torch.float32, device=x.device)
+    check(lib.lfsr_initconv_fwd(dev_ptr(x), dev_ptr(w), dev_ptr(out), 64, 0, B, A, h, wd, stream_ptr()), "initconv_fwd")
+    return out
+
+
+def upsample_head(f, w0, b0, w2, x_lr, A, s):
+    lib = load()
+    B, _, Hh, Ww = x_lr.shape
+    h, w = Hh // A, Ww // A
+    wf = torch.empty(s * s * 64, dtype=torch.float32, device=f.device)
+    bf = torch.empty(s * s, dtype=torch.float32, device=f.device)
+    check(lib.lfsr_fold_head(dev_ptr(w0), _opt(b0), dev_ptr(w2), dev_ptr(wf), dev_ptr(bf), 64, s, stream_ptr()), "fold_head")
+    out = torch.empty((B, 1, Hh * s, Ww * s), dtype=torch.float32, device=f.device)
+    check(lib.lfsr_upsample_head_fwd(dev_ptr(f), f.shape[1], 0, dev_ptr(wf), dev_ptr(bf), dev_ptr(x_lr), dev_ptr(out), B, A, h, w, s, stream_ptr()),
+          "upsample_head_fwd")
+    return out

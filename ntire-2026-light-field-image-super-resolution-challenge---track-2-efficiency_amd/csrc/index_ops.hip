@@ -1,0 +1,291 @@
+// a1-a7: bit-exact integer-indexing primitives on the reference's NCHW layouts, plus the
+// NCHW <-> VCL (view-major channel-last) converters.  All HBM-bound gathers: one thread per OUTPUT
+// element group, stores fully coalesced, loads touch whole lines within a block.
+#include "lfsr_common.h"
+
+namespace {
+
+// period-2n edge-including mirror (np.pad 'symmetric'); utils/utils.py:137-149 builds it from flips
+__device__ __forceinline__ int sym_index(int i, int n) {
+  int p = 2 * n;
+  int r = i % p;
+  if (r < 0) r += p;
+  return r < n ? r : p - 1 - r;
+}
+
+// ---- a1 / a2 --------------------------------------------------------------------------------
+// to_macpi = 1: out[b,c,y*A+u,x*A+v] = in[b,c,u*h+y,v*w+x]   (DistgSSR.py:145-155)
+// to_macpi = 0: out[b,c,u*h+y,v*w+x] = in[b,c,y*A+u,x*A+v]   (DistgSSR.py:134-142)
+template <typename T, int TO_MACPI>
+__global__ __launch_bounds__(256) void k_sai_macpi(const T* __restrict__ in, T* __restrict__ out, int planes, int A, int h, int w) {
+  const int Wd = A * w, Hd = A * h;
+  const long long total = (long long)planes * Hd * Wd;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int col = (int)(i % Wd);
+    long long t = i / Wd;
+    int row = (int)(t % Hd);
+    long long pl = t / Hd;
+    int srow, scol;
+    if (TO_MACPI) {
+      int y = row / A, u = row - y * A, x = col / A, v = col - x * A;
+      srow = u * h + y; scol = v * w + x;
+    } else {
+      int u = row / h, y = row - u * h, v = col / w, x = col - v * w;
+      srow = y * A + u; scol = x * A + v;
+    }
+    out[i] = in[(pl * Hd + srow) * Wd + scol];
+  }
+}
+
+// ---- a3: out[b,c,y*r+i,x*r+j] = in[b,c*r*r+i*r+j,y,x] ------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_pixel_shuffle2d(const T* __restrict__ in, T* __restrict__ out, int BC, int r, int H, int W) {
+  const int Wo = W * r, Ho = H * r;
+  const long long total = (long long)BC * Ho * Wo;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int xo = (int)(idx % Wo);
+    long long t = idx / Wo;
+    int yo = (int)(t % Ho);
+    long long bc = t / Ho;
+    int y = yo / r, i = yo - y * r, x = xo / r, j = xo - x * r;
+    out[idx] = in[((bc * r * r + i * r + j) * H + y) * W + x];
+  }
+}
+
+// ---- a4: out[b,c,y,x*f+k] = in[b,k*C+c,y,x] ----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_pixel_shuffle1d(const T* __restrict__ in, T* __restrict__ out, int B, int C, int f, int H, int W) {
+  const int Wo = W * f;
+  const long long total = (long long)B * C * H * Wo;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int xo = (int)(idx % Wo);
+    long long t = idx / Wo;
+    int y = (int)(t % H);
+    t /= H;
+    int c = (int)(t % C);
+    int b = (int)(t / C);
+    int x = xo / f, k = xo - x * f;
+    out[idx] = in[(((long long)b * f * C + (long long)k * C + c) * H + y) * W + x];
+  }
+}
+
+// ---- a5 -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_image_extend(const T* __restrict__ in, T* __restrict__ out, int N, int h, int w, int top, int left, int Ho, int Wo) {
+  const long long total = (long long)N * Ho * Wo;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int xo = (int)(idx % Wo);
+    long long t = idx / Wo;
+    int yo = (int)(t % Ho);
+    long long n = t / Ho;
+    out[idx] = in[(n * h + sym_index(yo - top, h)) * w + sym_index(xo - left, w)];
+  }
+}
+
+// ---- a6: sub[n1,n2,a1*P+y,a2*P+x] = data[a1*h0+sym(n1*S+y-bdr,h0), a2*w0+sym(n2*S+x-bdr,w0)] ----
+template <typename T>
+__global__ __launch_bounds__(256) void k_lf_divide(const T* __restrict__ in, T* __restrict__ out, int A, int h0, int w0, int P, int S, int bdr, int numU, int numV) {
+  const int AP = A * P;
+  const long long total = (long long)numU * numV * AP * AP;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int col = (int)(idx % AP);
+    long long t = idx / AP;
+    int row = (int)(t % AP);
+    t /= AP;
+    int n2 = (int)(t % numV), n1 = (int)(t / numV);
+    int a1 = row / P, y = row - a1 * P, a2 = col / P, x = col - a2 * P;
+    int sy = sym_index(n1 * S + y - bdr, h0), sx = sym_index(n2 * S + x - bdr, w0);
+    out[idx] = in[((long long)a1 * h0 + sy) * ((long long)A * w0) + (long long)a2 * w0 + sx];
+  }
+}
+
+// ---- a7: out[a1,a2,Y,X] = sub[Y/S', X/S', a1*pz+bdr'+Y%S', a2*pz+bdr'+X%S'] ----------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_lf_integrate(const T* __restrict__ in, T* __restrict__ out, int A, int numU, int numV, int pz, int stride, int bdr, int h, int w) {
+  const long long total = (long long)A * A * h * w;
+  const int AP = A * pz;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int X = (int)(idx % w);
+    long long t = idx / w;
+    int Y = (int)(t % h);
+    t /= h;
+    int a2 = (int)(t % A), a1 = (int)(t / A);
+    int n1 = Y / stride, yy = Y - n1 * stride, n2 = X / stride, xx = X - n2 * stride;
+    out[idx] = in[(((long long)n1 * numV + n2) * AP + a1 * pz + bdr + yy) * AP + a2 * pz + bdr + xx];
+  }
+}
+
+// ---- NCHW <-> VCL --------------------------------------------------------------------------------
+// One block = 64 consecutive pixels of one view-plane row group x all C channels through an LDS tile, so
+// both the NCHW side (pixels contiguous) and the VCL side (channels contiguous) move whole lines.
+template <int TO_VCL>
+__global__ __launch_bounds__(256) void k_nchw_vcl(const float* __restrict__ src, float* __restrict__ dst, int stride, int choff,
+                                                  int B, int C, int A, int h, int w, int layout) {
+  __shared__ float tile[64][65];
+  const int AA = A * A;
+  const long long npix = (long long)B * AA * h * w;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int Hd = A * h, Wd = A * w;
+  auto nchw_off = [&](long long p, int c) -> long long {
+    int x = (int)(p % w);
+    long long t = p / w;
+    int y = (int)(t % h);
+    t /= h;
+    int view = (int)(t % AA);
+    int b = (int)(t / AA);
+    int u = view / A, v = view - u * A;
+    int row = layout == 0 ? u * h + y : y * A + u;
+    int col = layout == 0 ? v * w + x : x * A + v;
+    return (((long long)b * C + c) * Hd + row) * Wd + col;
+  };
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  if (TO_VCL) {
+    for (int cc = ty; cc < 64; cc += 4) {  // read: pixel fastest
+      long long p = p0 + tx;
+      int c = c0 + cc;
+      tile[cc][tx] = (p < npix && c < C) ? src[nchw_off(p, c)] : 0.f;
+    }
+    __syncthreads();
+    for (int pp = ty; pp < 64; pp += 4) {  // write: channel fastest
+      long long p = p0 + pp;
+      int c = c0 + tx;
+      if (p < npix && c < C) dst[p * stride + choff + c] = tile[tx][pp];
+    }
+  } else {
+    for (int pp = ty; pp < 64; pp += 4) {
+      long long p = p0 + pp;
+      int c = c0 + tx;
+      tile[tx][pp] = (p < npix && c < C) ? src[p * stride + choff + c] : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+      long long p = p0 + tx;
+      int c = c0 + cc;
+      if (p < npix && c < C) dst[nchw_off(p, c)] = tile[cc][tx];
+    }
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  long long b = (total + 255) / 256;
+  if (b > 256LL * 32) b = 256LL * 32;  // grid-stride the rest
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+#define DISPATCH_ELEM(KERNEL, GRID, STREAM, ...)                                                        \
+  do {                                                                                                  \
+    if (elem_bytes == 4)                                                                                \
+      hipLaunchKernelGGL((KERNEL<uint32_t>), dim3(GRID), dim3(256), 0, STREAM, (const uint32_t*)in, (uint32_t*)out, __VA_ARGS__); \
+    else                                                                                                \
+      hipLaunchKernelGGL((KERNEL<uint16_t>), dim3(GRID), dim3(256), 0, STREAM, (const uint16_t*)in, (uint16_t*)out, __VA_ARGS__); \
+  } while (0)
+
+extern "C" {
+
+const char* lfsr_version(void) { return "lfsr_hip 0.1 gfx950 (fp32 MFMA 32x32x2)"; }
+
+static int bad_elem(int e) { return !(e == 2 || e == 4); }
+
+int lfsr_sai2macpi(const void* in, void* out, int B, int C, int A, int h, int w, int elem_bytes, void* stream) {
+  if (!in || !out || B < 0 || C < 0 || A <= 0 || h <= 0 || w <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  long long total = (long long)B * C * A * h * A * w;
+  if (total == 0) return LFSR_OK;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((k_sai_macpi<uint32_t, 1>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint32_t*)in, (uint32_t*)out, B * C, A, h, w);
+  else
+    hipLaunchKernelGGL((k_sai_macpi<uint16_t, 1>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint16_t*)in, (uint16_t*)out, B * C, A, h, w);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_macpi2sai(const void* in, void* out, int B, int C, int A, int h, int w, int elem_bytes, void* stream) {
+  if (!in || !out || B < 0 || C < 0 || A <= 0 || h <= 0 || w <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  long long total = (long long)B * C * A * h * A * w;
+  if (total == 0) return LFSR_OK;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((k_sai_macpi<uint32_t, 0>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint32_t*)in, (uint32_t*)out, B * C, A, h, w);
+  else
+    hipLaunchKernelGGL((k_sai_macpi<uint16_t, 0>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint16_t*)in, (uint16_t*)out, B * C, A, h, w);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_pixel_shuffle2d(const void* in, void* out, int B, int C, int r, int H, int W, int elem_bytes, void* stream) {
+  if (!in || !out || B < 0 || C < 0 || r <= 0 || H <= 0 || W <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  long long total = (long long)B * C * H * r * W * r;
+  if (total == 0) return LFSR_OK;
+  DISPATCH_ELEM(k_pixel_shuffle2d, grid_for(total), lfsr_stream(stream), B * C, r, H, W);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_pixel_shuffle1d(const void* in, void* out, int B, int C, int f, int H, int W, int elem_bytes, void* stream) {
+  if (!in || !out || B < 0 || C < 0 || f <= 0 || H <= 0 || W <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  long long total = (long long)B * C * H * W * f;
+  if (total == 0) return LFSR_OK;
+  DISPATCH_ELEM(k_pixel_shuffle1d, grid_for(total), lfsr_stream(stream), B, C, f, H, W);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_image_extend(const void* in, void* out, int N, int h, int w, int top, int bottom, int left, int right,
+                      int elem_bytes, void* stream) {
+  if (!in || !out || N < 0 || h <= 0 || w <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  int Ho = h + top + bottom, Wo = w + left + right;
+  long long total = (long long)N * Ho * Wo;
+  if (total == 0) return LFSR_OK;
+  DISPATCH_ELEM(k_image_extend, grid_for(total), lfsr_stream(stream), N, h, w, top, left, Ho, Wo);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_lf_divide(const void* in, void* out, int A, int h0, int w0, int P, int S, int elem_bytes, int* num_u, int* num_v, void* stream) {
+  if (A <= 0 || h0 <= 0 || w0 <= 0 || P <= 0 || S <= 0 || P < S || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  int bdr = (P - S) / 2;
+  int numU = (h0 + bdr * 2 - 1) / S, numV = (w0 + bdr * 2 - 1) / S;
+  if (num_u) *num_u = numU;
+  if (num_v) *num_v = numV;
+  if (!out) return LFSR_OK;
+  if (!in) return LFSR_E_ARG;
+  // the reference's unfold count equals numU*numV only when the padded extent admits exactly numU windows
+  // (utils/utils.py:159-164 rearrange would raise otherwise)
+  if ((h0 + 2 * bdr + S - 1 - P) / S + 1 != numU || (w0 + 2 * bdr + S - 1 - P) / S + 1 != numV) return LFSR_E_ARG;
+  long long total = (long long)numU * numV * A * P * A * P;
+  if (total == 0) return LFSR_OK;
+  DISPATCH_ELEM(k_lf_divide, grid_for(total), lfsr_stream(stream), A, h0, w0, P, S, bdr, numU, numV);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_lf_integrate(const void* in, void* out, int A, int numU, int numV, int pz, int stride, int h, int w, int elem_bytes, void* stream) {
+  if (!in || !out || A <= 0 || numU <= 0 || numV <= 0 || pz <= 0 || stride <= 0 || pz < stride || h <= 0 || w <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  if (h > numU * stride || w > numV * stride) return LFSR_E_ARG;
+  int bdr = (pz - stride) / 2;
+  long long total = (long long)A * A * h * w;
+  DISPATCH_ELEM(k_lf_integrate, grid_for(total), lfsr_stream(stream), A, numU, numV, pz, stride, bdr, h, w);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_nchw_to_vcl(const float* in, float* out, int out_stride, int out_choff, int B, int C, int A, int h, int w, int layout, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || A <= 0 || h <= 0 || w <= 0 || (layout != 0 && layout != 1) || out_stride < out_choff + C) return LFSR_E_ARG;
+  long long npix = (long long)B * A * A * h * w;
+  dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((C + 63) / 64));
+  hipLaunchKernelGGL((k_nchw_vcl<1>), grid, dim3(256), 0, lfsr_stream(stream), in, out, out_stride, out_choff, B, C, A, h, w, layout);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_vcl_to_nchw(const float* in, int in_stride, int in_choff, float* out, int B, int C, int A, int h, int w, int layout, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || A <= 0 || h <= 0 || w <= 0 || (layout != 0 && layout != 1) || in_stride < in_choff + C) return LFSR_E_ARG;
+  long long npix = (long long)B * A * A * h * w;
+  dim3 grid((unsigned)((npix + 63) / 64), (unsigned)((C + 63) / 64));
+  hipLaunchKernelGGL((k_nchw_vcl<0>), grid, dim3(256), 0, lfsr_stream(stream), in, out, in_stride, in_choff, B, C, A, h, w, layout);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+"""DistgSSR plugin (drop-in for the reference's ``model/SR/DistgSSR.py``).
+
+Same plugin surface -- ``get_model(args)``, ``get_loss(args)``, ``weights_init(m)`` (reference
+train.py:48-50,94; DistgSSR.py:14-36,158-170) -- and the same ``state_dict`` key names / shapes
+(SURVEY 8c), so reference checkpoints load unchanged.  The modules below are parameter containers only:
+``forward`` hands the tensors to the gfx950 HIP library through the C ABI (lfsr_amd.capi); none of the
+``nn.Conv2d.forward`` paths is ever executed and there is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from lfsr_amd import capi
+
+
+def _dil_conv(cin, cout, A):
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=1, dilation=A, padding=A, bias=False)
+
+
+class _Holder(nn.Module):
+    """Parameter container whose forward must never run."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the HIP path computes this layer")
+
+
+class _Block(_Holder):
+    # DisentgBlock, DistgSSR.py:73-111 (module creation order kept so seeded default init matches)
+    def __init__(self, A, ch):
+        super().__init__()
+        spa, ang, epi = ch, ch // 4, ch // 2
+        self.SpaConv = nn.Sequential(_dil_conv(ch, spa, A), nn.LeakyReLU(0.1, inplace=True), _dil_conv(spa, spa, A), nn.LeakyReLU(0.1, inplace=True))
+        self.AngConv = nn.Sequential(nn.Conv2d(ch, ang, kernel_size=A, stride=A, padding=0, bias=False), nn.LeakyReLU(0.1, inplace=True),
+                                     nn.Conv2d(ang, A * A * ang, kernel_size=1, bias=False), nn.LeakyReLU(0.1, inplace=True), nn.PixelShuffle(A))
+        self.EPIConv = nn.Sequential(nn.Conv2d(ch, epi, kernel_size=[1, A * A], stride=[1, A], padding=[0, A * (A - 1) // 2], bias=False),
+                                     nn.LeakyReLU(0.1, inplace=True), nn.Conv2d(epi, A * epi, kernel_size=1, bias=False),
+                                     nn.LeakyReLU(0.1, inplace=True), nn.Identity())
+        self.fuse = nn.Sequential(nn.Conv2d(spa + ang + 2 * epi, ch, kernel_size=1, bias=False), nn.LeakyReLU(0.1, inplace=True), _dil_conv(ch, ch, A))
+
+
+class _Group(_Holder):
+    # DisentgGroup, DistgSSR.py:56-70
+    def __init__(self, n_block, A, ch):
+        super().__init__()
+        self.Block = nn.Sequential(*[_Block(A, ch) for _ in range(n_block)])
+        self.conv = _dil_conv(ch, ch, A)
+
+
+class _Cascade(_Holder):
+    # CascadeDisentgGroup, DistgSSR.py:39-53
+    def __init__(self, n_group, n_block, A, ch):
+        super().__init__()
+        self.Group = nn.Sequential(*[_Group(n_block, A, ch) for _ in range(n_group)])
+        self.conv = _dil_conv(ch, ch, A)
+
+
+class get_model(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        channels, n_group, n_block = 64, 4, 4
+        self.angRes = args.angRes_in
+        self.factor = args.scale_factor
+        self.init_conv = _dil_conv(1, channels, self.angRes)
+        self.disentg = _Cascade(n_group, n_block, self.angRes, channels)
+        self.upsample = nn.Sequential(nn.Conv2d(channels, channels * self.factor ** 2, kernel_size=1),
+                                      nn.PixelShuffle(self.factor), nn.Conv2d(channels, 1, kernel_size=1, bias=False))
+        self._rt = None
+        self._rt_version = None
+
+    # -- HIP runtime plumbing ------------------------------------------------------------------------
+    def _runtime(self, device):
+        if self._rt is None:
+            self._rt = capi.DistgSSRRuntime(self.angRes, self.factor)
+        ver = (device, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        if ver != self._rt_version:   # (re)pack after load_state_dict / .to() / an optimizer step
+            self._rt.load_state(self.state_dict().items(), device)
+            self._rt_version = ver
+        return self._rt
+
+    def forward(self, x, info=None):
+        if not x.is_cuda:
+            raise capi.LfsrError("DistgSSR: input must live on the MI355X (no CPU fallback in the HIP path)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("DistgSSR HIP backward is not built yet: call under torch.no_grad()")
+        return self._runtime(x.device).forward(x.float() if x.dtype != torch.float32 else x)
+
+
+class get_loss(nn.Module):
+    # DistgSSR.py:158-166
+    def __init__(self, args):
+        super().__init__()
+        self.criterion_Loss = torch.nn.L1Loss()
+
+    def forward(self, SR, HR, criterion_data=[]):
+        return self.criterion_Loss(SR, HR)
+
+
+def weights_init(m):
+    # DistgSSR.py:169-170: a no-op upstream
+    pass

@@ -1,0 +1,198 @@
+"""GPU: DistgSSR operator classes and the whole forward through the C ABI against the numpy oracle
+(reference formulation, fp64) and the golden vectors produced by the reference itself.
+
+Tolerance (BASELINE north_star: fp32 conv path within 0.01 dB PSNR): we hold the sharper gates
+max|err| <= 1e-4 and PSNR(hip, ref) >= 80 dB and check |dPSNR| <= 0.01 dB against a label."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lfsr_amd import capi
+from lfsr_amd.synth import synth_input, synth_tensor
+from oracle import lfsr_oracle as O
+from tests.helpers import model_case, psnr
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def to_vcl(x_macpi, A):
+    return capi.nchw_to_vcl(dev(x_macpi), A, 1)
+
+
+def from_vcl(v, B, C, A, h, w, choff=0):
+    return capi.vcl_to_nchw(v, B, C, A, h, w, 1, choff).cpu().numpy()
+
+
+GEOMS = [(1, 5, 8, 8), (2, 3, 6, 8), (1, 5, 32, 32), (3, 2, 5, 7)]
+
+
+@pytest.mark.parametrize("B,A,h,w", GEOMS)
+def test_conv3x3(B, A, h, w):
+    x = rnd((B, 64, A * h, A * w), 1)
+    wt = rnd((64, 64, 3, 3), 2, 0.05)
+    r1 = rnd((B, 64, A * h, A * w), 3)
+    ref = O.leaky_relu(O.conv2d(x.astype(np.float64), wt.astype(np.float64), dilation=(A, A), padding=(A, A)), 0.1)
+    wp = capi.pack_conv_weight(dev(wt))
+    y = capi.conv3x3(to_vcl(x, A), wp, B * A * A, h, w, slope=0.1)
+    assert np.abs(from_vcl(y, B, 64, A, h, w) - ref).max() < ATOL
+    # residual form: conv + r1 + r1 (two residual inputs), no activation
+    ref2 = O.conv2d(x.astype(np.float64), wt.astype(np.float64), dilation=(A, A), padding=(A, A)) + 2 * r1
+    rv = to_vcl(r1, A)
+    y2 = capi.conv3x3(to_vcl(x, A), wp, B * A * A, h, w, slope=1.0, res1=rv, res2=rv)
+    assert np.abs(from_vcl(y2, B, 64, A, h, w) - ref2).max() < ATOL
+
+
+@pytest.mark.parametrize("B,A,h,w", GEOMS)
+def test_angconv(B, A, h, w):
+    x = rnd((B, 64, A * h, A * w), 4)
+    w1 = rnd((16, 64, A, A), 5, 0.03)
+    w2 = rnd((A * A * 16, 16, 1, 1), 6, 0.2)
+    x64 = x.astype(np.float64)
+    t = O.leaky_relu(O.conv2d(x64, w1.astype(np.float64), stride=(A, A)), 0.1)
+    ref = O.pixel_shuffle(O.leaky_relu(O.conv2d(t, w2.astype(np.float64)), 0.1), A)
+    out = torch.zeros((B * A * A * h * w, 144), device="cuda")
+    capi.angconv(to_vcl(x, A), capi.pack_conv_weight(dev(w1)), capi.pack_conv_weight(dev(w2), perm=1, ch=16), B, A, h, w, 0.1, out, 64)
+    assert np.abs(from_vcl(out, B, 16, A, h, w, choff=64) - ref).max() < ATOL
+    assert float(out[:, :64].abs().max()) == 0.0 and float(out[:, 80:].abs().max()) == 0.0   # wrote only its slice
+
+
+@pytest.mark.parametrize("vertical", [0, 1])
+@pytest.mark.parametrize("B,A,h,w", GEOMS)
+def test_epiconv(B, A, h, w, vertical):
+    x = rnd((B, 64, A * h, A * w), 7)
+    w1 = rnd((32, 64, 1, A * A), 8, 0.03)
+    w2 = rnd((A * 32, 32, 1, 1), 9, 0.15)
+
+    def epi(t):
+        e = O.leaky_relu(O.conv2d(t, w1.astype(np.float64), stride=(1, A), padding=(0, A * (A - 1) // 2)), 0.1)
+        return O.pixel_shuffle1d(O.leaky_relu(O.conv2d(e, w2.astype(np.float64)), 0.1), A)
+    x64 = x.astype(np.float64)
+    ref = epi(np.ascontiguousarray(x64.transpose(0, 1, 3, 2))).transpose(0, 1, 3, 2) if vertical else epi(x64)
+    out = torch.zeros((B * A * A * h * w, 144), device="cuda")
+    capi.epiconv(to_vcl(x, A), capi.pack_conv_weight(dev(w1)), capi.pack_conv_weight(dev(w2)), B, A, h, w, vertical, 0.1, out, 112)
+    assert np.abs(from_vcl(out, B, 32, A, h, w, choff=112) - ref).max() < ATOL
+
+
+@pytest.mark.parametrize("cin,N", [(144, 64), (64, 64), (64, 40), (32, 160), (16, 400)])
+def test_pointwise(cin, N):
+    M = 1000
+    x = rnd((M, cin), 10)
+    wt = rnd((N, cin, 1, 1), 11, 0.1)
+    b = rnd((N,), 12)
+    ref = O.leaky_relu(x.astype(np.float64) @ wt.reshape(N, cin).astype(np.float64).T + b, 0.1)
+    y = capi.pointwise(dev(x), cin, capi.pack_conv_weight(dev(wt)), N, slope=0.1, bias=dev(b))
+    assert np.abs(y.cpu().numpy() - ref).max() < ATOL
+
+
+@pytest.mark.parametrize("B,A,h,w", GEOMS)
+def test_initconv(B, A, h, w):
+    x = synth_input((B, 1, A * h, A * w), 1)
+    wt = rnd((64, 1, 3, 3), 13, 0.3)
+    ref = O.conv2d(O.sai2macpi(x.astype(np.float64), A), wt.astype(np.float64), dilation=(A, A), padding=(A, A))
+    y = capi.initconv(dev(x), dev(wt), A)
+    assert np.abs(from_vcl(y, B, 64, A, h, w) - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("s", [2, 4])
+@pytest.mark.parametrize("B,A,h,w", GEOMS[:3])
+def test_upsample_head(B, A, h, w, s):
+    f = rnd((B, 64, A * h, A * w), 14)           # MacPI features
+    x = synth_input((B, 1, A * h, A * w), 1)
+    w0 = rnd((64 * s * s, 64, 1, 1), 15, 0.1)
+    b0 = rnd((64 * s * s,), 16, 0.1)
+    w2 = rnd((1, 64, 1, 1), 17, 0.1)
+    f64 = f.astype(np.float64)
+    up = O.conv2d(O.pixel_shuffle(O.conv2d(O.macpi2sai(f64, A), w0.astype(np.float64), b0.astype(np.float64)), s), w2.astype(np.float64))
+    ref = up + O.interp_bilinear(x.astype(np.float64), s)
+    y = capi.upsample_head(to_vcl(f, A), dev(w0), dev(b0), dev(w2), dev(x), A, s)
+    assert np.abs(y.cpu().numpy() - ref).max() < ATOL
+
+
+# ---- whole model ------------------------------------------------------------------------------------
+
+def build_runtime(case, sd):
+    rt = capi.DistgSSRRuntime(case["A"], case["s"])
+    rt.load_state([(k, dev(v)) for k, v in sd.items()], torch.device("cuda", 0))
+    return rt
+
+
+TAPS = ["init_conv", "b0_out", "g0_out", "disentg_out"]
+
+
+@pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
+def test_distgssr_small_vs_golden_and_oracle(tag):
+    case, sd, x, npz = model_case("DistgSSR", tag)
+    rt = build_runtime(case, sd)
+    y, bufs = rt.forward(dev(x), taps=[True] * 5)
+    y = y.cpu().numpy()
+    otaps = {}
+    ref = O.distgssr_forward(x, sd, case["A"], case["s"], taps=otaps)
+    for i, name in enumerate(TAPS):
+        assert np.abs(bufs[i].cpu().numpy() - otaps[name]).max() < ATOL, name
+    cat = np.concatenate([otaps["b0_spa"], otaps["b0_ang"], otaps["b0_epih"], otaps["b0_epiv_t"].transpose(0, 1, 3, 2)], axis=1)
+    assert np.abs(bufs[4].cpu().numpy() - cat).max() < ATOL
+    gold = npz[tag + "_out"]
+    assert np.abs(y - ref).max() < ATOL
+    assert np.abs(y - gold).max() < ATOL
+    assert psnr(y, gold) >= 80.0
+
+
+def test_distgssr_full_patch():
+    """BASELINE config geometry (5x5, 32x32 -> 128x128, x4) at B=2 against the oracle and the reference's
+    checksummed full-size output (strided sample)."""
+    case, sd, x1, npz = model_case("DistgSSR", "full")
+    x = np.concatenate([x1, synth_input(x1.shape, seed=5)], axis=0)
+    rt = build_runtime(case, sd)
+    y = rt.forward(dev(x)).cpu().numpy()
+    assert y.shape == (2, 1, 640, 640)
+    assert np.abs(y[:1, :, ::8, ::8] - npz["full_sample"]).max() < ATOL        # the reference itself
+    ref = O.distgssr_forward(x, sd, 5, 4, dtype=np.float64)
+    assert np.abs(y - ref).max() < ATOL
+    assert psnr(y, ref) >= 80.0
+    label = synth_input(y.shape, seed=2)
+    assert abs(psnr(y, label) - psnr(ref, label)) <= 0.01
+    # batch independence: patch 0 alone gives the same bits as patch 0 inside the batch
+    y0 = rt.forward(dev(x[:1])).cpu().numpy()
+    assert np.array_equal(y0, y[:1])
+
+
+def test_distgssr_plugin_surface():
+    """model/SR/DistgSSR.py mirror: get_model / get_loss / weights_init, state_dict round trip, no-grad forward."""
+    import importlib
+    from argparse import Namespace
+    sys.path.insert(0, capi._HERE)
+    try:
+        M = importlib.import_module("model.SR.DistgSSR")
+    finally:
+        sys.path.remove(capi._HERE)
+    case, sd, x, npz = model_case("DistgSSR", "a3h6w8s2")
+    net = M.get_model(Namespace(angRes_in=3, angRes_out=3, scale_factor=2))
+    net.apply(M.weights_init)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to("cuda:0").eval()
+    with torch.no_grad():
+        y = net(dev(x), [3, 3])
+    assert np.abs(y.cpu().numpy() - npz["a3h6w8s2_out"]).max() < ATOL
+    with pytest.raises(capi.LfsrError):
+        with torch.no_grad():
+            net(torch.from_numpy(x), [3, 3])          # CPU tensor: no fallback
+    loss = M.get_loss(None)(y, torch.zeros_like(y), [3, 3])
+    assert loss.ndim == 0
+    # weights changed in place -> repacked
+    with torch.no_grad():
+        net.upsample[2].weight.mul_(0.0)
+        y2 = net(dev(x), [3, 3])
+    ref_skip = O.interp_bilinear(x.astype(np.float64), 2)
+    assert np.abs(y2.cpu().numpy() - ref_skip).max() < 1e-5
