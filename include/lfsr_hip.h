@@ -146,6 +146,14 @@ int lfsr_distgssr_forward(lfsr_distgssr* ctx, const float* x, float* out, int B,
 int lfsr_distgssr_forward_taps(lfsr_distgssr* ctx, const float* x, float* out, int B, int h, int w,
                                void* workspace, size_t workspace_bytes, float* const* taps, void* stream);
 
+/* Per-operator-class timing with hipEvents recorded on the launch stream around every launch of the
+ * forward (measurement aid for bench.py's roofline line; off by default).
+ * classes: 0 conv3x3, 1 angconv, 2 epiconv, 3 pointwise (fuse.0), 4 init_conv, 5 upsample head. */
+#define LFSR_DISTG_NCLASS 6
+int lfsr_distgssr_profile(lfsr_distgssr* ctx, int enable);   /* enable/disable; drops recorded events */
+/* waits for the recorded events, returns summed milliseconds and launch counts per class, then resets */
+int lfsr_distgssr_profile_read(lfsr_distgssr* ctx, double* ms, long long* launches);
+
 #ifdef __cplusplus
 }
 #endif

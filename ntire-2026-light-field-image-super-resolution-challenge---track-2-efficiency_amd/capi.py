@@ -47,6 +47,8 @@ SIGNATURES = {
     "lfsr_distgssr_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "lfsr_distgssr_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "lfsr_distgssr_forward_taps": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, C.POINTER(c_p), c_p]),
+    "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
+    "lfsr_distgssr_profile_read": (c_i, [c_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
 
 _lib = None
@@ -254,6 +256,18 @@ class DistgSSRRuntime:
             n = self.lib.lfsr_distgssr_workspace_bytes(self.ctx, B, h, w)
             self.ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
         return self.ws[key]
+
+    PROFILE_CLASSES = ("conv3x3", "angconv", "epiconv", "pointwise", "init_conv", "upsample_head")
+
+    def profile(self, enable):
+        check(self.lib.lfsr_distgssr_profile(self.ctx, int(enable)), "distgssr_profile")
+
+    def profile_read(self):
+        """-> {class: (total_ms, launches)} from hipEvents recorded on the launch stream; resets."""
+        ms = (C.c_double * 6)()
+        n = (C.c_longlong * 6)()
+        check(self.lib.lfsr_distgssr_profile_read(self.ctx, ms, n), "distgssr_profile_read")
+        return {k: (ms[i], n[i]) for i, k in enumerate(self.PROFILE_CLASSES)}
 
     def forward(self, x, taps=None):
         """x (B,1,A*h,A*w) fp32 CUDA -> (B,1,A*h*s,A*w*s).  taps: optional list of 5 bools."""

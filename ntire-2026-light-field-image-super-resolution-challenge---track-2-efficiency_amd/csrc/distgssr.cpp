@@ -24,6 +24,16 @@ struct lfsr_distgssr {
   size_t packed_floats = 0, off_wf = 0, off_bf = 0;
   float* packed = nullptr;
   bool finalized = false;
+  bool profiling = false;
+  struct Ev { int cls; hipEvent_t a, b; };
+  std::vector<Ev> evs;          // recorded this profiling session
+  std::vector<hipEvent_t> free_evs;
+  hipEvent_t get_ev() {
+    if (!free_evs.empty()) { hipEvent_t e = free_evs.back(); free_evs.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
 
   void add(const std::string& k, int O, int Cc, int T, int perm, int ch, bool raw) {
     Slot sl;
@@ -69,7 +79,37 @@ int lfsr_distgssr_create(lfsr_distgssr** out, int A, int scale, int n_group, int
   return LFSR_OK;
 }
 
-void lfsr_distgssr_destroy(lfsr_distgssr* c) { delete c; }
+void lfsr_distgssr_destroy(lfsr_distgssr* c) {
+  if (!c) return;
+  for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto e : c->free_evs) (void)hipEventDestroy(e);
+  delete c;
+}
+
+int lfsr_distgssr_profile(lfsr_distgssr* c, int enable) {
+  if (!c) return LFSR_E_ARG;
+  for (auto& e : c->evs) { c->free_evs.push_back(e.a); c->free_evs.push_back(e.b); }
+  c->evs.clear();
+  c->profiling = enable != 0;
+  return LFSR_OK;
+}
+
+int lfsr_distgssr_profile_read(lfsr_distgssr* c, double* ms, long long* launches) {
+  if (!c || !ms || !launches) return LFSR_E_ARG;
+  for (int i = 0; i < LFSR_DISTG_NCLASS; ++i) { ms[i] = 0.0; launches[i] = 0; }
+  for (auto& e : c->evs) {
+    hipError_t err = hipEventSynchronize(e.b);
+    if (err != hipSuccess) return LFSR_HIP_ERR(err);
+    float t = 0.f;
+    err = hipEventElapsedTime(&t, e.a, e.b);
+    if (err != hipSuccess) return LFSR_HIP_ERR(err);
+    ms[e.cls] += t;
+    launches[e.cls] += 1;
+    c->free_evs.push_back(e.a); c->free_evs.push_back(e.b);
+  }
+  c->evs.clear();
+  return LFSR_OK;
+}
 
 size_t lfsr_distgssr_packed_bytes(const lfsr_distgssr* c) { return c ? c->packed_floats * sizeof(float) : 0; }
 
@@ -145,6 +185,19 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
   const float L = 0.1f;  // LeakyReLU(0.1), DistgSSR.py:80-101
   int rc;
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
+#define PROF(cls, call)                                                              \
+  do {                                                                               \
+    if (c->profiling) {                                                              \
+      lfsr_distgssr::Ev ev{cls, c->get_ev(), c->get_ev()};                           \
+      (void)hipEventRecord(ev.a, lfsr_stream(stream));                                     \
+      rc = (call);                                                                   \
+      (void)hipEventRecord(ev.b, lfsr_stream(stream));                                     \
+      c->evs.push_back(ev);                                                          \
+    } else {                                                                         \
+      rc = (call);                                                                   \
+    }                                                                                \
+    if (rc) return rc;                                                               \
+  } while (0)
   auto tap = [&](int which, const float* buf, int stride, int C) -> int {
     if (!taps || !taps[which]) return LFSR_OK;
     return lfsr_vcl_to_nchw(buf, stride, 0, taps[which], B, C, A, h, w, 1, stream);
@@ -159,7 +212,7 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
   };
 
   float* F0 = pool[0];
-  RC(lfsr_initconv_fwd(x, c->w("init_conv.weight"), F0, 64, 0, B, A, h, w, stream));
+  PROF(4, lfsr_initconv_fwd(x, c->w("init_conv.weight"), F0, 64, 0, B, A, h, w, stream));
   RC(tap(0, F0, 64, 64));
   const float* cur = F0;
   for (int g = 0; g < c->G; ++g) {
@@ -167,30 +220,31 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
     for (int b = 0; b < c->NB; ++b) {
       std::string p = "disentg.Group." + std::to_string(g) + ".Block." + std::to_string(b) + ".";
       float* o = pick(F0, gin, cur);
-      RC(conv(cur, p + "SpaConv.0.weight", T, 64, 0, nullptr, L));
-      RC(conv(T, p + "SpaConv.2.weight", CAT, 144, 0, nullptr, L));
-      RC(lfsr_angconv_fwd(cur, 64, 0, c->w(p + "AngConv.0.weight"), c->w(p + "AngConv.2.weight"), A16, CAT, 144, 64, B, A, h, w, L, stream));
-      RC(lfsr_epiconv_fwd(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), E32, CAT, 144, 80, B, A, h, w, 0, L, stream));
-      RC(lfsr_epiconv_fwd(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), E32, CAT, 144, 112, B, A, h, w, 1, L, stream));
+      PROF(0, conv(cur, p + "SpaConv.0.weight", T, 64, 0, nullptr, L));
+      PROF(0, conv(T, p + "SpaConv.2.weight", CAT, 144, 0, nullptr, L));
+      PROF(1, lfsr_angconv_fwd(cur, 64, 0, c->w(p + "AngConv.0.weight"), c->w(p + "AngConv.2.weight"), A16, CAT, 144, 64, B, A, h, w, L, stream));
+      PROF(2, lfsr_epiconv_fwd(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), E32, CAT, 144, 80, B, A, h, w, 0, L, stream));
+      PROF(2, lfsr_epiconv_fwd(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), E32, CAT, 144, 112, B, A, h, w, 1, L, stream));
       if (g == 0 && b == 0) RC(tap(4, CAT, 144, 144));
-      RC(lfsr_pointwise_fwd(CAT, 144, 0, 144, c->w(p + "fuse.0.weight"), nullptr, T, 64, 0, nimg * h * w, 64, L, stream));
-      RC(conv(T, p + "fuse.2.weight", o, 64, 0, cur, 1.0f));
+      PROF(3, lfsr_pointwise_fwd(CAT, 144, 0, 144, c->w(p + "fuse.0.weight"), nullptr, T, 64, 0, nimg * h * w, 64, L, stream));
+      PROF(0, conv(T, p + "fuse.2.weight", o, 64, 0, cur, 1.0f));
       cur = o;
       if (g == 0 && b == 0) RC(tap(1, cur, 64, 64));
     }
     float* o = pick(F0, gin, cur);
-    RC(conv(cur, "disentg.Group." + std::to_string(g) + ".conv.weight", o, 64, 0, gin, 1.0f));
+    PROF(0, conv(cur, "disentg.Group." + std::to_string(g) + ".conv.weight", o, 64, 0, gin, 1.0f));
     cur = o;
     if (g == 0) RC(tap(2, cur, 64, 64));
   }
   {
     float* o = pick(F0, cur, cur);
-    RC(conv(cur, "disentg.conv.weight", o, 64, 0, F0, 1.0f));
+    PROF(0, conv(cur, "disentg.conv.weight", o, 64, 0, F0, 1.0f));
     cur = o;
     RC(tap(3, cur, 64, 64));
   }
-  RC(lfsr_upsample_head_fwd(cur, 64, 0, c->packed + c->off_wf, c->packed + c->off_bf, x, out, B, A, h, w, c->s, stream));
+  PROF(5, lfsr_upsample_head_fwd(cur, 64, 0, c->packed + c->off_wf, c->packed + c->off_bf, x, out, B, A, h, w, c->s, stream));
 #undef RC
+#undef PROF
   return LFSR_OK;
 }
 

@@ -190,9 +190,10 @@ const char* lfsr_version(void) { return "lfsr_hip 0.1 gfx950 (fp32 MFMA 32x32x2)
 static int bad_elem(int e) { return !(e == 2 || e == 4); }
 
 int lfsr_sai2macpi(const void* in, void* out, int B, int C, int A, int h, int w, int elem_bytes, void* stream) {
-  if (!in || !out || B < 0 || C < 0 || A <= 0 || h <= 0 || w <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  if (B < 0 || C < 0 || A <= 0 || h <= 0 || w <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
   long long total = (long long)B * C * A * h * A * w;
-  if (total == 0) return LFSR_OK;
+  if (total == 0) return LFSR_OK;  // empty tensors carry NULL pointers
+  if (!in || !out) return LFSR_E_ARG;
   if (elem_bytes == 4)
     hipLaunchKernelGGL((k_sai_macpi<uint32_t, 1>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint32_t*)in, (uint32_t*)out, B * C, A, h, w);
   else
@@ -202,9 +203,10 @@ int lfsr_sai2macpi(const void* in, void* out, int B, int C, int A, int h, int w,
 }
 
 int lfsr_macpi2sai(const void* in, void* out, int B, int C, int A, int h, int w, int elem_bytes, void* stream) {
-  if (!in || !out || B < 0 || C < 0 || A <= 0 || h <= 0 || w <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  if (B < 0 || C < 0 || A <= 0 || h <= 0 || w <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
   long long total = (long long)B * C * A * h * A * w;
-  if (total == 0) return LFSR_OK;
+  if (total == 0) return LFSR_OK;  // empty tensors carry NULL pointers
+  if (!in || !out) return LFSR_E_ARG;
   if (elem_bytes == 4)
     hipLaunchKernelGGL((k_sai_macpi<uint32_t, 0>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint32_t*)in, (uint32_t*)out, B * C, A, h, w);
   else
@@ -214,18 +216,20 @@ int lfsr_macpi2sai(const void* in, void* out, int B, int C, int A, int h, int w,
 }
 
 int lfsr_pixel_shuffle2d(const void* in, void* out, int B, int C, int r, int H, int W, int elem_bytes, void* stream) {
-  if (!in || !out || B < 0 || C < 0 || r <= 0 || H <= 0 || W <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  if (B < 0 || C < 0 || r <= 0 || H <= 0 || W <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
   long long total = (long long)B * C * H * r * W * r;
   if (total == 0) return LFSR_OK;
+  if (!in || !out) return LFSR_E_ARG;
   DISPATCH_ELEM(k_pixel_shuffle2d, grid_for(total), lfsr_stream(stream), B * C, r, H, W);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
 
 int lfsr_pixel_shuffle1d(const void* in, void* out, int B, int C, int f, int H, int W, int elem_bytes, void* stream) {
-  if (!in || !out || B < 0 || C < 0 || f <= 0 || H <= 0 || W <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  if (B < 0 || C < 0 || f <= 0 || H <= 0 || W <= 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
   long long total = (long long)B * C * H * W * f;
   if (total == 0) return LFSR_OK;
+  if (!in || !out) return LFSR_E_ARG;
   DISPATCH_ELEM(k_pixel_shuffle1d, grid_for(total), lfsr_stream(stream), B, C, f, H, W);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
@@ -233,10 +237,11 @@ int lfsr_pixel_shuffle1d(const void* in, void* out, int B, int C, int f, int H, 
 
 int lfsr_image_extend(const void* in, void* out, int N, int h, int w, int top, int bottom, int left, int right,
                       int elem_bytes, void* stream) {
-  if (!in || !out || N < 0 || h <= 0 || w <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  if (N < 0 || h <= 0 || w <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0 || bad_elem(elem_bytes)) return LFSR_E_ARG;
   int Ho = h + top + bottom, Wo = w + left + right;
   long long total = (long long)N * Ho * Wo;
   if (total == 0) return LFSR_OK;
+  if (!in || !out) return LFSR_E_ARG;
   DISPATCH_ELEM(k_image_extend, grid_for(total), lfsr_stream(stream), N, h, w, top, left, Ho, Wo);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;

@@ -115,10 +115,11 @@ def conv2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
     xp = np.zeros((B, C, H + 2 * ph, W + 2 * pw), dtype=x.dtype)
     xp[:, :, ph:ph + H, pw:pw + W] = x
     out = np.zeros((B, O, Ho * Wo), dtype=x.dtype)
+    wt = np.ascontiguousarray(w.transpose(2, 3, 0, 1))                 # (kh, kw, O, C): contiguous GEMM operands
     for i in range(kh):
         for j in range(kw):
             sl = xp[:, :, i * dh:i * dh + sh * (Ho - 1) + 1:sh, j * dw:j * dw + sw * (Wo - 1) + 1:sw]
-            out += np.matmul(w[:, :, i, j], sl.reshape(B, C, Ho * Wo))
+            out += np.matmul(wt[i, j], np.ascontiguousarray(sl).reshape(B, C, Ho * Wo))
     out = out.reshape(B, O, Ho, Wo)
     if bias is not None:
         out = out + bias.reshape(1, O, 1, 1)

@@ -107,3 +107,13 @@ def test_interp_against_torch():
         tc = F.interpolate(torch.from_numpy(x), scale_factor=s, mode="bicubic", align_corners=False).numpy()
         assert np.abs(O.interp_bilinear(x, s) - tb).max() < 1e-12
         assert np.abs(O.interp_bicubic(x, s) - tc).max() < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
+def test_torch_port_distgssr(tag):
+    """the torch-CPU form of the oracle (bench.py's cpu_baseline) against the reference's output"""
+    torch = pytest.importorskip("torch")
+    from oracle import lfsr_torch_port as T
+    case, sd, x, npz = model_case("DistgSSR", tag)
+    y = T.distgssr_forward(torch.from_numpy(x), {k: torch.from_numpy(v) for k, v in sd.items()}, case["A"], case["s"]).numpy()
+    assert np.abs(y - npz[tag + "_out"]).max() < 1e-5
