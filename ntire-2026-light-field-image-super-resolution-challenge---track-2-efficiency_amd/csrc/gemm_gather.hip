@@ -22,9 +22,16 @@
 // h takes k = 8j+4h..8j+4h+3, which is a K permutation applied to A and W alike, so 4 MFMAs consume it.
 // LDS: (128 + BN) * 272 B  = 52 KB at NT=2  ->  3 blocks/CU, which is what hides the two barriers per
 // stage.  MFMA-bound by design: 128 x 64 x 64 x 2 flop per stage against 48 KB of L2->LDS traffic.
+#include <stdlib.h>
+
 #include "lfsr_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// conv3x3_halo.hip
+int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
+                             const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                             int n_img, int h, int w, float slope, hipStream_t st);
 
 namespace {
 
@@ -393,6 +400,15 @@ int lfsr_conv3x3_fwd(const float* x, int x_stride, int x_choff, const float* w_p
   if (!x || !w_packed || !y || n_img <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < y_choff + 64 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if ((long long)n_img * h * w >= (1LL << 31) / 4) return LFSR_E_ARG;
+  {
+    // v2 halo-tile kernel needs 16-B aligned channel vectors on every operand; LFSR_CONV3X3=gather forces v1 (A/B runs)
+    const char* sel = getenv("LFSR_CONV3X3");
+    const bool force_v1 = sel && sel[0] == 'g';
+    const bool al = !((y_stride | y_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!r2 || !((r2_stride | r2_choff) & 3));
+    if (al && !force_v1)
+      return lfsr_conv3x3_halo_launch(x, x_stride, x_choff, w_packed, y, y_stride, y_choff, r1, r1_stride, r1_choff, r2, r2_stride, r2_choff,
+                                      n_img, h, w, slope, lfsr_stream(stream));
+  }
   GemmArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.bias = nullptr;
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
