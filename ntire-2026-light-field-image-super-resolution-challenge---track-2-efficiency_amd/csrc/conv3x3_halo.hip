@@ -22,7 +22,7 @@ constexpr int TR = 8, TC = 32, LROW = 68;
 constexpr int HALO_PIX = (TR + 2) * (TC + 2);                 // 340
 constexpr int SA_FLOATS = HALO_PIX * LROW;                    // 23120
 constexpr int SB_FLOATS = 64 * LROW;                          // per buffer
-constexpr int SMEM_BYTES = (SA_FLOATS + 2 * SB_FLOATS) * 4;   // 127296
+constexpr int SMEM_BYTES = (SA_FLOATS + 3 * SB_FLOATS) * 4;   // 144704: halo + 3 weight buffers
 
 struct ConvArgs {
   const float* X; int x_stride; int x_choff;
@@ -80,16 +80,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
   float4 hv[11];
 #pragma unroll
   for (int i = 0; i < 11; ++i) hv[i] = halo_load(i, img, y0, x0);
-  float4 nb0 = *reinterpret_cast<const float4*>(p.Wp + r16 * 64 + c16 * 4);
-  float4 nb1 = *reinterpret_cast<const float4*>(p.Wp + (r16 + 32) * 64 + c16 * 4);
+  // weight stream: tap t's slab lives in LDS buffer t%3 (9%3==0, so the stream is periodic across tiles);
+  // slab t+1 is written at the START of tap t from registers filled during tap t-1, and made visible by ONE
+  // barrier placed in the MIDDLE of tap t's MFMA stream (fragments already in flight -> the pipe does not drain).
+  {
+    float4 w0 = *reinterpret_cast<const float4*>(p.Wp + r16 * 64 + c16 * 4);
+    float4 w1 = *reinterpret_cast<const float4*>(p.Wp + (r16 + 32) * 64 + c16 * 4);
+    *reinterpret_cast<float4*>(sB + r16 * LROW + c16 * 4) = w0;
+    *reinterpret_cast<float4*>(sB + (r16 + 32) * LROW + c16 * 4) = w1;
+  }
+  float4 nb0 = *reinterpret_cast<const float4*>(p.Wp + 64 * 64 + r16 * 64 + c16 * 4);          // slab 1
+  float4 nb1 = *reinterpret_cast<const float4*>(p.Wp + 64 * 64 + (r16 + 32) * 64 + c16 * 4);
 
   while (true) {
     // ---- registers -> LDS: this tile's halo and tap 0's weights ------------------------------------
 #pragma unroll
     for (int i = 0; i < 11; ++i)
       if (hoff[i] >= 0) *reinterpret_cast<float4*>(sA + hoff[i] * LROW + c16 * 4) = hv[i];
-    *reinterpret_cast<float4*>(sB + r16 * LROW + c16 * 4) = nb0;
-    *reinterpret_cast<float4*>(sB + (r16 + 32) * LROW + c16 * 4) = nb1;
     // LDS-only barrier: the previous tile's output stores stay in flight (a __syncthreads would drain vmcnt)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -102,14 +109,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
     float4 res[8];
+    float4 fa, fb0, fb1;
     const int yy = y0 + wave;
     const long long row_base = (long long)img * p.H * p.W + (long long)yy * p.W + x0;
 
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      // weights of the next tap (tap 8: tap 0 of the next tile) fly while this tap computes
+      // slab tap+1 (loaded during the previous tap) -> LDS buffer (tap+1)%3, last read two taps ago;
+      // then start fetching slab tap+2
       {
-        const float* wsrc = p.Wp + (long long)((tap + 1) % 9) * 64 * 64;
+        float* bN = sB + ((tap + 1) % 3) * SB_FLOATS;
+        *reinterpret_cast<float4*>(bN + r16 * LROW + c16 * 4) = nb0;
+        *reinterpret_cast<float4*>(bN + (r16 + 32) * LROW + c16 * 4) = nb1;
+        const float* wsrc = p.Wp + (long long)((tap + 2) % 9) * 64 * 64;
         nb0 = *reinterpret_cast<const float4*>(wsrc + r16 * 64 + c16 * 4);
         nb1 = *reinterpret_cast<const float4*>(wsrc + (r16 + 32) * 64 + c16 * 4);
       }
@@ -129,30 +141,47 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
+      // MFMA stream, software-pipelined by hand: the fragments of step (tap, j+1) are requested from LDS
+      // BEFORE the 8 MFMAs of step (tap, j) issue, so the two co-resident waves of a SIMD never both sit
+      // in an LDS wait with the matrix pipe empty (they run in lock-step after every barrier).
       const int dy = tap / 3 - 1, dx = tap % 3 - 1;
       const float* aT = aBase + (dy * (TC + 2) + dx) * LROW;
-      const float* bT = bBase + (tap & 1) * SB_FLOATS;
+      const float* bT = bBase + (tap % 3) * SB_FLOATS;
+      if (tap == 0) {
+        fa = *reinterpret_cast<const float4*>(aT);
+        fb0 = *reinterpret_cast<const float4*>(bT);
+        fb1 = *reinterpret_cast<const float4*>(bT + 32 * LROW);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float4 a = *reinterpret_cast<const float4*>(aT + 8 * j);
-        float4 b0 = *reinterpret_cast<const float4*>(bT + 8 * j);
-        float4 b1 = *reinterpret_cast<const float4*>(bT + 32 * LROW + 8 * j);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        if (j == 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // publishes slab tap+1
+        float4 na, nb0f, nb1f;
+        if (j < 7) {
+          na = *reinterpret_cast<const float4*>(aT + 8 * (j + 1));
+          nb0f = *reinterpret_cast<const float4*>(bT + 8 * (j + 1));
+          nb1f = *reinterpret_cast<const float4*>(bT + 32 * LROW + 8 * (j + 1));
+        } else if (tap < 8) {   // first fragments of the next tap (its slab was published by this tap's barrier)
+          const int ndy = (tap + 1) / 3 - 1, ndx = (tap + 1) % 3 - 1;
+          const float* naT = aBase + (ndy * (TC + 2) + ndx) * LROW;
+          const float* nbT = bBase + ((tap + 1) % 3) * SB_FLOATS;
+          na = *reinterpret_cast<const float4*>(naT);
+          nb0f = *reinterpret_cast<const float4*>(nbT);
+          nb1f = *reinterpret_cast<const float4*>(nbT + 32 * LROW);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads first ...
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb1.w, acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs of this step
+        if (j < 7 || tap < 8) { fa = na; fb0 = nb0f; fb1 = nb1f; }
       }
-      if (tap < 8) {   // the other weight buffer was last read during tap-1, which every wave left at the last barrier
-        float* bN = sB + ((tap + 1) & 1) * SB_FLOATS;
-        *reinterpret_cast<float4*>(bN + r16 * LROW + c16 * 4) = nb0;
-        *reinterpret_cast<float4*>(bN + (r16 + 32) * LROW + c16 * 4) = nb1;
-      }
-      __syncthreads();
     }
+    __syncthreads();   // all waves are done reading the halo (and tap 8's slab) before the epilogue reuses the region
 
     // ---- epilogue: accumulators -> LDS [pixel][channel] -> 16-B stores (256 B contiguous per pixel) ----
     // C/D layout: channel n = lane&31 (+32 for acc1), pixel column = (reg&3) + 8*(reg>>2) + 4*half
