@@ -109,6 +109,13 @@ int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
                      float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical,
                      float slope, void* stream);
 
+/* Both EPI passes of a DisentgBlock (DistgSSR.py:107-108) in one launch: horizontal result to channel slice
+ * choff_h, vertical (transposed application, same weights) to choff_v of y.  Uses the fused LDS-tile kernel
+ * when (A odd, A <= 5, h,w <= 32), else two gather-GEMM launches per pass through tmp (may be NULL if fused). */
+int lfsr_epiconv_hv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                        float* tmp, float* y, int y_stride, int choff_h, int choff_v, int B, int A, int h, int w,
+                        float slope, void* stream);
+
 /* init_conv, DistgSSR.py:22,32 fused with SAI2MacPI (DistgSSR.py:31): x (B,1,A*h,A*w) SAI mosaic NCHW,
  * w (64,1,3,3) raw PyTorch layout -> y VCL 64 channels. */
 int lfsr_initconv_fwd(const float* x, const float* w, float* y, int y_stride, int y_choff, int B, int A, int h, int wd,

@@ -35,6 +35,7 @@ SIGNATURES = {
     "lfsr_pointwise_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_angconv_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_epiconv_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_epiconv_hv_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_initconv_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_fold_head": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "lfsr_upsample_head_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -341,6 +342,14 @@ def epiconv(x, w1p, w2p, B, A, h, w, vertical, slope, out, out_choff):
     tmp = torch.empty((B * A * h * w, 32), dtype=torch.float32, device=x.device)
     check(lib.lfsr_epiconv_fwd(dev_ptr(x), x.shape[1], 0, dev_ptr(w1p), dev_ptr(w2p), dev_ptr(tmp), dev_ptr(out), out.shape[1], out_choff,
                                B, A, h, w, int(vertical), slope, stream_ptr()), "epiconv_fwd")
+    return out
+
+
+def epiconv_hv(x, w1p, w2p, B, A, h, w, slope, out, choff_h, choff_v):
+    lib = load()
+    tmp = torch.empty((B * A * h * w, 32), dtype=torch.float32, device=x.device)
+    check(lib.lfsr_epiconv_hv_fwd(dev_ptr(x), x.shape[1], 0, dev_ptr(w1p), dev_ptr(w2p), dev_ptr(tmp), dev_ptr(out), out.shape[1], choff_h, choff_v,
+                                  B, A, h, w, slope, stream_ptr()), "epiconv_hv_fwd")
     return out
 
 

@@ -223,8 +223,7 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
       PROF(0, conv(cur, p + "SpaConv.0.weight", T, 64, 0, nullptr, L));
       PROF(0, conv(T, p + "SpaConv.2.weight", CAT, 144, 0, nullptr, L));
       PROF(1, lfsr_angconv_fwd(cur, 64, 0, c->w(p + "AngConv.0.weight"), c->w(p + "AngConv.2.weight"), A16, CAT, 144, 64, B, A, h, w, L, stream));
-      PROF(2, lfsr_epiconv_fwd(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), E32, CAT, 144, 80, B, A, h, w, 0, L, stream));
-      PROF(2, lfsr_epiconv_fwd(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), E32, CAT, 144, 112, B, A, h, w, 1, L, stream));
+      PROF(2, lfsr_epiconv_hv_fwd(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), E32, CAT, 144, 80, 112, B, A, h, w, L, stream));
       if (g == 0 && b == 0) RC(tap(4, CAT, 144, 144));
       PROF(3, lfsr_pointwise_fwd(CAT, 144, 0, 144, c->w(p + "fuse.0.weight"), nullptr, T, 64, 0, nimg * h * w, 64, L, stream));
       PROF(0, conv(T, p + "fuse.2.weight", o, 64, 0, cur, 1.0f));

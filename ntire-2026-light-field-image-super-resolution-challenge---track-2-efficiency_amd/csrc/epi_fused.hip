@@ -1,0 +1,205 @@
+// Fused EPIConv branch (model/SR/DistgSSR.py:91-97 and its transposed application :108) on VCL, fp32 MFMA:
+//   t = lrelu(conv 1xA^2, stride (1,A), pad A(A-1)/2, 64->32);  y = lrelu(1x1 32->32A);  PixelShuffle1D(A)
+// for BOTH the horizontal pass (EPI lines along x, weights applied to the MacPI tensor) and the vertical pass
+// (lines along y, the reference transposes the tensor and reuses the same weights) in ONE launch, writing each
+// pass straight into its 32-channel slice of the 144-channel concat buffer.
+//
+// In VCL the 1xA^2 conv is a 1-D conv along the EPI line with A taps (dxi) over an (A views x 64)-channel
+// input: source of tap k = A*dxi + v' for output position t is view v', position t + dxi - (A-1)/2 (odd A).
+// One 512-thread block = 8 EPI lines (one per wave: 32 positions = the 32 A-rows of a 32x32x2 MFMA, N = 32).
+// K is walked view by view ("stage" v'): the 8 x (32+A-1) input vectors of that view and the A weight slabs
+// (k = v', A+v', ...) are staged in LDS once and reused by the A taps at shifted addresses (5x reuse), with the
+// next stage prefetched into registers while the current one computes.  After the last stage the 32x32 result
+// tile is LeakyReLU'd, transposed through LDS into MFMA A-operand order and multiplied by the 1x1 weights
+// (20 KB, read straight from L1/L2), then scattered by chunk (= PixelShuffle1D) to the A views.
+#include "lfsr_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int LINES = 8, LROW = 68, TROW = 36;
+
+struct EpiArgs {
+  const float* X; int x_stride; int x_choff;
+  const float* W1;    // [A*A][32][64]  (tap k, n, c)
+  const float* W2;    // [32A][32]      (n = chunk*32 + c, k): the 1x1 weights, row-major as packed by lfsr_pack_conv_weight
+  float* Y; int y_stride; int choffH; int choffV;
+  int B, A, H, W;
+  int tilesH, tilesV;   // tiles per pass; blockIdx.x < tilesH -> horizontal
+  float slope;
+};
+
+__global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int A = p.A, PP = 32 + A - 1, pad = (A - 1) / 2;
+  float* sA = smem;                              // [LINES][PP][LROW]
+  float* sW = smem + LINES * PP * LROW;          // [A][32][LROW]
+  int* sLine = reinterpret_cast<int*>(sW + A * 32 * LROW);   // [LINES] source/dest base pixel or -1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = tid & 15, r16 = tid >> 4;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int HW = p.H * p.W;
+
+  const bool vert = (int)blockIdx.x >= p.tilesH;
+  const int tile = vert ? blockIdx.x - p.tilesH : blockIdx.x;
+  const int len = vert ? p.H : p.W;                 // positions along the line
+  const int across = vert ? p.W : p.H;              // lines per (b, u|v) group
+  const int nlines = p.B * A * across;
+  const int vstride = vert ? A * HW : HW;           // pixel stride between the A source views / dest chunks
+  const int pstride = vert ? p.W : 1;               // pixel stride along the line
+  const int choff = vert ? p.choffV : p.choffH;
+
+  if (tid < LINES) {
+    int ln = tile * LINES + tid;
+    int base = -1;
+    if (ln < nlines) {
+      int q = ln / across, o = ln - q * across;     // horizontal: q = b*A+u, o = y;  vertical: q = b*A+v, o = x
+      if (!vert) base = q * A * HW + o * p.W;
+      else { int b = q / A, v = q - b * A; base = (b * A * A + v) * HW + o; }
+    }
+    sLine[tid] = base;
+  }
+  __syncthreads();
+
+  const int nvec = LINES * PP;                      // input vectors per stage
+  float4 ra[9], rw[5];                              // A <= 5 fast path sizes (checked by the launcher)
+  auto prefetch = [&](int vv) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      int vec = r16 + 32 * i;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec < nvec) {
+        int l = vec / PP, pp = vec - l * PP;
+        int t = pp - pad;
+        int base = sLine[l];
+        if (base >= 0 && t >= 0 && t < len)
+          ra[i] = *reinterpret_cast<const float4*>(p.X + ((long long)base + (long long)vv * vstride + (long long)t * pstride) * p.x_stride + p.x_choff + c16 * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int row = r16 + 32 * i;                       // (dxi, n)
+      rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < A * 32) {
+        int dxi = row >> 5, n = row & 31;
+        rw[i] = *reinterpret_cast<const float4*>(p.W1 + ((long long)(A * dxi + vv) * 32 + n) * 64 + c16 * 4);
+      }
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const float* aBase = sA + (wave * PP + l31) * LROW + 4 * half;
+  const float* bBase = sW + l31 * LROW + 4 * half;
+
+  prefetch(0);
+  for (int vv = 0; vv < A; ++vv) {
+    if (vv > 0) __syncthreads();                    // previous stage fully consumed
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      int vec = r16 + 32 * i;
+      if (vec < nvec) *reinterpret_cast<float4*>(sA + vec * LROW + c16 * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int row = r16 + 32 * i;
+      if (row < A * 32) *reinterpret_cast<float4*>(sW + row * LROW + c16 * 4) = rw[i];
+    }
+    __syncthreads();
+    if (vv + 1 < A) prefetch(vv + 1);               // flies under this stage's MFMAs
+    for (int dxi = 0; dxi < A; ++dxi) {
+      const float* aT = aBase + dxi * LROW;
+      const float* bT = bBase + dxi * 32 * LROW;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float4 a = *reinterpret_cast<const float4*>(aT + 8 * j);
+        float4 b = *reinterpret_cast<const float4*>(bT + 8 * j);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                   // stage area is dead: reuse it for the transposition
+
+  // ---- stage 2: t = lrelu(acc) [pos][32] -> LDS (row stride 36) -> A-operand fragments --------------------
+  float* sT = sA + wave * 32 * TROW;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int pos = (r & 3) + 8 * (r >> 2) + 4 * half;
+    float v = acc[r];
+    sT[pos * TROW + l31] = v >= 0.f ? v : v * p.slope;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float4 fa[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const float4*>(sT + l31 * TROW + 8 * j + 4 * half);
+
+  const int base = sLine[wave];
+  for (int nt = 0; nt < A; ++nt) {                  // chunk nt = destination view along the EPI's angular axis
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 b = *reinterpret_cast<const float4*>(p.W2 + (nt * 32 + l31) * 32 + 8 * j + 4 * half);   // 20 KB, L1/L2 resident
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].x, b.x, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].y, b.y, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].z, b.z, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].w, b.w, o, 0, 0, 0);
+    }
+    if (base >= 0) {
+      const long long dview = (long long)base + (long long)nt * vstride;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int pos = (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (pos < len) {
+          float v = o[r];
+          v = v >= 0.f ? v : v * p.slope;
+          p.Y[(dview + (long long)pos * pstride) * p.y_stride + choff + l31] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+size_t lfsr_epi_fused_smem(int A) {
+  return (size_t)(LINES * (32 + A - 1) * LROW + A * 32 * LROW) * 4 + LINES * 4 + 32;
+}
+
+bool lfsr_epi_fused_ok(int A, int h, int w) {
+  return (A & 1) && A >= 1 && A <= 5 && h <= 32 && w <= 32 && lfsr_epi_fused_smem(A) <= 160 * 1024;
+}
+
+int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,
+                          int choffH, int choffV, int B, int A, int h, int w, int which, float slope, hipStream_t st) {
+  // which: 1 = horizontal only, 2 = vertical only, 3 = both
+  if (!lfsr_epi_fused_ok(A, h, w)) return LFSR_E_ARG;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  const int smem = (int)lfsr_epi_fused_smem(5);
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_fused), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  EpiArgs p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.W1 = w1_packed; p.W2 = w2_packed;
+  p.Y = y; p.y_stride = y_stride; p.choffH = choffH; p.choffV = choffV;
+  p.B = B; p.A = A; p.H = h; p.W = w; p.slope = slope;
+  p.tilesH = (which & 1) ? (B * A * h + LINES - 1) / LINES : 0;
+  p.tilesV = (which & 2) ? (B * A * w + LINES - 1) / LINES : 0;
+  int grid = p.tilesH + p.tilesV;
+  if (grid <= 0) return LFSR_E_ARG;
+  hipLaunchKernelGGL(k_epi_fused, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

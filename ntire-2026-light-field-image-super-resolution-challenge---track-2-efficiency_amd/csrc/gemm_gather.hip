@@ -33,6 +33,11 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              int n_img, int h, int w, float slope, hipStream_t st);
 
+// epi_fused.hip
+bool lfsr_epi_fused_ok(int A, int h, int w);
+int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,
+                          int choffH, int choffV, int B, int A, int h, int w, int which, float slope, hipStream_t st);
+
 namespace {
 
 enum { IN_SAME = 0, IN_CONV3 = 1, IN_ANG = 2, IN_EPIH = 3, IN_EPIV = 4 };
@@ -454,11 +459,8 @@ int lfsr_angconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
   return launch_gemm<IN_SAME, OUT_VIEWS, 16, 1>(q, st);
 }
 
-int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
-                     float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical, float slope, void* stream) {
-  if (!x || !w1_packed || !w2_packed || !tmp || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
-  if (x_stride < x_choff + 64 || y_stride < y_choff + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
-  hipStream_t st = lfsr_stream(stream);
+static int epiconv_gather(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                          float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical, float slope, hipStream_t st) {
   GemmArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w1_packed;
   p.Y = tmp; p.y_stride = 32; p.y_choff = 0;
@@ -470,6 +472,33 @@ int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
   q.Y = y; q.y_stride = y_stride; q.y_choff = y_choff;
   q.M = B * A * h * w; q.N = 32 * A; q.Npad = npad32(q.N); q.A = A; q.AA = A * A; q.H = h; q.W = w; q.ntaps = 1; q.CH = 32; q.slope = slope;
   return vertical ? launch_gemm<IN_SAME, OUT_EPIV, 32, 1>(q, st) : launch_gemm<IN_SAME, OUT_EPIH, 32, 1>(q, st);
+}
+
+static bool epi_use_fused(int A, int h, int w) {
+  const char* sel = getenv("LFSR_EPI");   // LFSR_EPI=gather forces the two-launch gather-GEMM path (A/B runs)
+  return !(sel && sel[0] == 'g') && lfsr_epi_fused_ok(A, h, w);
+}
+
+int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                     float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical, float slope, void* stream) {
+  if (!x || !w1_packed || !w2_packed || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
+  if (x_stride < x_choff + 64 || y_stride < y_choff + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
+  if (epi_use_fused(A, h, w))
+    return lfsr_epi_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, y, y_stride, y_choff, y_choff, B, A, h, w, vertical ? 2 : 1, slope, lfsr_stream(stream));
+  if (!tmp) return LFSR_E_ARG;
+  return epiconv_gather(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, y_choff, B, A, h, w, vertical, slope, lfsr_stream(stream));
+}
+
+int lfsr_epiconv_hv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                        float* tmp, float* y, int y_stride, int choff_h, int choff_v, int B, int A, int h, int w, float slope, void* stream) {
+  if (!x || !w1_packed || !w2_packed || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
+  if (x_stride < x_choff + 64 || y_stride < choff_h + 32 || y_stride < choff_v + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
+  if (epi_use_fused(A, h, w))
+    return lfsr_epi_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, y, y_stride, choff_h, choff_v, B, A, h, w, 3, slope, lfsr_stream(stream));
+  if (!tmp) return LFSR_E_ARG;
+  int rc = epiconv_gather(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, choff_h, B, A, h, w, 0, slope, lfsr_stream(stream));
+  if (rc) return rc;
+  return epiconv_gather(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, choff_v, B, A, h, w, 1, slope, lfsr_stream(stream));
 }
 
 int lfsr_initconv_fwd(const float* x, const float* w, float* y, int y_stride, int y_choff, int B, int A, int h, int wd, void* stream) {

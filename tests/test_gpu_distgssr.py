@@ -85,6 +85,25 @@ def test_epiconv(B, A, h, w, vertical):
     assert np.abs(from_vcl(out, B, 32, A, h, w, choff=112) - ref).max() < ATOL
 
 
+@pytest.mark.parametrize("B,A,h,w", GEOMS)
+def test_epiconv_hv_one_launch(B, A, h, w):
+    x = rnd((B, 64, A * h, A * w), 27)
+    w1 = rnd((32, 64, 1, A * A), 28, 0.03)
+    w2 = rnd((A * 32, 32, 1, 1), 29, 0.15)
+
+    def epi(t):
+        e = O.leaky_relu(O.conv2d(t, w1.astype(np.float64), stride=(1, A), padding=(0, A * (A - 1) // 2)), 0.1)
+        return O.pixel_shuffle1d(O.leaky_relu(O.conv2d(e, w2.astype(np.float64)), 0.1), A)
+    x64 = x.astype(np.float64)
+    refh = epi(x64)
+    refv = epi(np.ascontiguousarray(x64.transpose(0, 1, 3, 2))).transpose(0, 1, 3, 2)
+    out = torch.zeros((B * A * A * h * w, 144), device="cuda")
+    capi.epiconv_hv(to_vcl(x, A), capi.pack_conv_weight(dev(w1)), capi.pack_conv_weight(dev(w2)), B, A, h, w, 0.1, out, 80, 112)
+    assert np.abs(from_vcl(out, B, 32, A, h, w, choff=80) - refh).max() < ATOL
+    assert np.abs(from_vcl(out, B, 32, A, h, w, choff=112) - refv).max() < ATOL
+    assert float(out[:, :80].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("cin,N", [(144, 64), (64, 64), (64, 40), (32, 160), (16, 400)])
 def test_pointwise(cin, N):
     M = 1000
