@@ -1,0 +1,92 @@
+"""CPU: the patch-sharded scene dispatcher (host logic) with 2 gloo ranks.  The tensor ops are the numpy
+oracle's LFdivide/LFintegrate (stand-ins for the HIP kernels, injected), the 'model' is a deterministic
+nearest-neighbour x4 upsampler, so the expected result is known in closed form."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lfsr_amd.dispatch import shard_range, sr_scene
+from oracle import lfsr_oracle as O
+
+
+class OracleOps:
+    @staticmethod
+    def divide(lr, A, patch, stride):
+        return torch.from_numpy(O.lf_divide(lr.numpy(), A, patch, stride))
+
+    @staticmethod
+    def integrate(sub, A, pz, stride, h, w):
+        return torch.from_numpy(O.lf_integrate(sub.numpy(), A, pz, stride, h, w))
+
+
+def fake_net(x, info=None):
+    # per-view nearest x4 of the SAI mosaic patch: (B,1,A*P,A*P) -> (B,1,A*P*4,A*P*4)
+    return x.repeat_interleave(4, 2).repeat_interleave(4, 3)
+
+
+def expected(lr, A):
+    h0, w0 = lr.shape[0] // A, lr.shape[1] // A
+    v = lr.reshape(A, h0, A, w0).permute(0, 2, 1, 3)
+    return v.repeat_interleave(4, 2).repeat_interleave(4, 3)
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 64, 70):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
+
+
+def test_single_rank_scene():
+    A = 5
+    lr = torch.arange(A * 40 * A * 33, dtype=torch.float32).reshape(A * 40, A * 33)
+    out = sr_scene(fake_net, lr, A, 4, ops=OracleOps, minibatch=4)
+    assert torch.equal(out, expected(lr, A))
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        A = 3
+        lr = torch.arange(A * 37 * A * 50, dtype=torch.float32).reshape(A * 37, A * 50)   # 3 x 4 = 12 patches... ragged split below
+        out = sr_scene(fake_net, lr, A, 4, ops=OracleOps, minibatch=5)
+        ok = torch.equal(out, expected(lr, A))
+        # ragged: 9 patches over 2 ranks (5 + 4)
+        lr2 = torch.arange(5 * 40 * 5 * 33, dtype=torch.float32).reshape(5 * 40, 5 * 33)
+        out2 = sr_scene(fake_net, lr2, 5, 4, ops=OracleOps, minibatch=2)
+        ok = ok and torch.equal(out2, expected(lr2, 5))
+        # max-over-ranks clock reduction used by bench.py
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok = ok and float(t.item()) == float(world)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_scene_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(0) is True and ret.get(1) is True
