@@ -153,6 +153,19 @@ int lfsr_distgssr_forward(lfsr_distgssr* ctx, const float* x, float* out, int B,
 int lfsr_distgssr_forward_taps(lfsr_distgssr* ctx, const float* x, float* out, int B, int h, int w,
                                void* workspace, size_t workspace_bytes, float* const* taps, void* stream);
 
+/* ---- training (config "DistgSSR x4 training, data-parallel"): forward that keeps the activations, and backward ----
+ * Gradients are written into ONE flat fp32 bucket in state_dict order (lfsr_distgssr_param_offset gives each
+ * parameter's span): exactly the buffer a data-parallel job hands to a single RCCL all-reduce.
+ * The workspace must be the same memory for forward_train and the backward that follows it. */
+size_t lfsr_distgssr_num_params(const lfsr_distgssr* ctx);
+int lfsr_distgssr_param_offset(const lfsr_distgssr* ctx, const char* key, size_t* offset, size_t* numel);
+size_t lfsr_distgssr_train_workspace_bytes(const lfsr_distgssr* ctx, int B, int h, int w);
+int lfsr_distgssr_forward_train(lfsr_distgssr* ctx, const float* x, float* out, int B, int h, int w,
+                                void* workspace, size_t workspace_bytes, void* stream);
+/* dout (B,1,A*h*s,A*w*s) = dLoss/dOut; grads: n_grads == lfsr_distgssr_num_params(ctx) floats, overwritten */
+int lfsr_distgssr_backward(lfsr_distgssr* ctx, const float* x, const float* dout, int B, int h, int w,
+                           void* workspace, size_t workspace_bytes, float* grads, size_t n_grads, void* stream);
+
 /* Per-operator-class timing with hipEvents recorded on the launch stream around every launch of the
  * forward (measurement aid for bench.py's roofline line; off by default).
  * classes: 0 conv3x3, 1 angconv, 2 epiconv, 3 pointwise (fuse.0), 4 init_conv, 5 upsample head. */

@@ -48,6 +48,11 @@ SIGNATURES = {
     "lfsr_distgssr_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "lfsr_distgssr_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "lfsr_distgssr_forward_taps": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, C.POINTER(c_p), c_p]),
+    "lfsr_distgssr_num_params": (c_sz, [c_p]),
+    "lfsr_distgssr_param_offset": (c_i, [c_p, C.c_char_p, C.POINTER(c_sz), C.POINTER(c_sz)]),
+    "lfsr_distgssr_train_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
+    "lfsr_distgssr_forward_train": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "lfsr_distgssr_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_sz, c_p]),
     "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
     "lfsr_distgssr_profile_read": (c_i, [c_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
@@ -257,6 +262,50 @@ class DistgSSRRuntime:
             n = self.lib.lfsr_distgssr_workspace_bytes(self.ctx, B, h, w)
             self.ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
         return self.ws[key]
+
+    # ---- training ---------------------------------------------------------------------------------
+    def num_params(self):
+        return self.lib.lfsr_distgssr_num_params(self.ctx)
+
+    def param_span(self, key):
+        off, n = c_sz(0), c_sz(0)
+        check(self.lib.lfsr_distgssr_param_offset(self.ctx, key.encode(), C.byref(off), C.byref(n)), f"param_offset({key})")
+        return off.value, n.value
+
+    def _train_workspace(self, B, h, w, device):
+        key = ("train", B, h, w, device)
+        if key not in self.ws:
+            self.ws.clear()
+            n = self.lib.lfsr_distgssr_train_workspace_bytes(self.ctx, B, h, w)
+            self.ws[key] = torch.empty(n, dtype=torch.uint8, device=device)
+        return self.ws[key]
+
+    def forward_train(self, x):
+        B, c1, Hh, Ww = x.shape
+        if c1 != 1 or Hh % self.A or Ww % self.A or x.dtype != torch.float32:
+            raise LfsrError(f"bad training input {tuple(x.shape)} {x.dtype}")
+        h, w = Hh // self.A, Ww // self.A
+        x = x.contiguous()
+        out = torch.empty((B, 1, Hh * self.scale, Ww * self.scale), dtype=torch.float32, device=x.device)
+        ws = self._train_workspace(B, h, w, x.device)
+        check(self.lib.lfsr_distgssr_forward_train(self.ctx, dev_ptr(x), dev_ptr(out), B, h, w, dev_ptr(ws), ws.numel(), stream_ptr()),
+              "distgssr_forward_train")
+        return out
+
+    def backward(self, x, dout, grads=None):
+        """dLoss/dOut -> flat fp32 gradient bucket (state_dict order).  Must follow forward_train(x) of the same x."""
+        B, _, Hh, Ww = x.shape
+        h, w = Hh // self.A, Ww // self.A
+        n = self.num_params()
+        if grads is None:
+            grads = torch.empty(n, dtype=torch.float32, device=x.device)
+        ws = self._train_workspace(B, h, w, x.device)
+        dout = dout.contiguous()
+        if dout.dtype != torch.float32:
+            dout = dout.float()
+        check(self.lib.lfsr_distgssr_backward(self.ctx, dev_ptr(x.contiguous()), dev_ptr(dout), B, h, w, dev_ptr(ws), ws.numel(),
+                                              dev_ptr(grads), n, stream_ptr()), "distgssr_backward")
+        return grads
 
     PROFILE_CLASSES = ("conv3x3", "angconv", "epiconv", "pointwise", "init_conv", "upsample_head")
 

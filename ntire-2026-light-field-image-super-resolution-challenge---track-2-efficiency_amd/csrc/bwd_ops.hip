@@ -1,0 +1,234 @@
+// Backward (data-gradient) wrappers over the gather-GEMM kernel, plus the small head / init_conv backward kernels.
+// Every data gradient of DistgSSR is again a gather-GEMM (the transposed index map of a gather is a gather), with the
+// weights packed transposed (lfsr_pack_weight_T / _chunkT) and two epilogue extras: the LeakyReLU' mask taken from the
+// saved forward activation, and in-place accumulation into the gradient buffer (R1 aliasing Y).
+#include "gemm_gather_kernel.h"
+#include "lfsr_internal.h"
+
+namespace {
+
+// dOut (B,1,A*h*s,A*w*s) HR mosaic -> g16[p][ij] rows (p = VCL pixel), and df[p][k] = sum_ij g16[p][ij] wf[ij][k]
+template <int S>
+__global__ __launch_bounds__(256) void k_head_bwd(const float* __restrict__ dout, const float* __restrict__ wf, float* __restrict__ df,
+                                                 float* __restrict__ g16, int B, int A, int h, int w) {
+  __shared__ float sw[S * S * 64];
+  for (int i = threadIdx.x; i < S * S * 64; i += 256) sw[i] = wf[i];
+  __syncthreads();
+  const long long npix = (long long)B * A * A * h * w;
+  const int Wo = A * w * S, Ho = A * h * S;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < npix * 16; g += (long long)gridDim.x * 256) {
+    long long pix = g >> 4;
+    int c4 = (int)(g & 15) * 4;
+    int x = (int)(pix % w);
+    long long t = pix / w;
+    int y = (int)(t % h);
+    t /= h;
+    int view = (int)(t % (A * A));
+    int b = (int)(t / (A * A));
+    int u = view / A, v = view - u * A;
+    const float* ob = dout + ((long long)b * Ho + (long long)(u * h + y) * S) * Wo + (long long)(v * w + x) * S;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        float gv = ob[(long long)i * Wo + j];
+        const float* wr = sw + (i * S + j) * 64 + c4;
+        a0 = fmaf(gv, wr[0], a0); a1 = fmaf(gv, wr[1], a1); a2 = fmaf(gv, wr[2], a2); a3 = fmaf(gv, wr[3], a3);
+        if (c4 == 0) g16[pix * 16 + i * S + j] = gv;
+      }
+    if (c4 == 0 && S * S < 16)
+      for (int q = S * S; q < 16; ++q) g16[pix * 16 + q] = 0.f;
+    *reinterpret_cast<float4*>(df + pix * 64 + c4) = make_float4(a0, a1, a2, a3);
+  }
+}
+
+// per-block column sums of a row-major (M, N<=16) matrix: partial[blk][N]
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ g, int M, int N, float* __restrict__ partial, int rows_per_blk) {
+  __shared__ float red[256];
+  const int col = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+  const int m0 = blockIdx.x * rows_per_blk, m1 = min(M, m0 + rows_per_blk);
+  float s = 0.f;
+  if (col < N)
+    for (int m = m0 + r0; m < m1; m += 16) s += g[(long long)m * N + col];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    for (int r = 0; r < 16; ++r) t += red[r * 16 + threadIdx.x];
+    if (threadIdx.x < N) partial[blockIdx.x * 16 + threadIdx.x] = t;
+  }
+}
+
+// gradients of the folded head back to upsample.0.{weight,bias} and upsample.2.weight (DistgSSR.py:24-27)
+__global__ void k_head_fold_bwd(const float* __restrict__ dWf, const float* __restrict__ partial, int nblk, const float* __restrict__ w0,
+                                const float* __restrict__ b0, const float* __restrict__ w2, float* __restrict__ dw0, float* __restrict__ db0,
+                                float* __restrict__ dw2, int s2) {
+  __shared__ float dbf[16];
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    if ((int)threadIdx.x < s2)
+      for (int b = 0; b < nblk; ++b) t += partial[b * 16 + threadIdx.x];
+    dbf[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const int C = 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * s2 * C; i += gridDim.x * blockDim.x) {
+    int k = i % C, row = i / C, c = row / s2, ij = row - c * s2;
+    dw0[i] = w2[c] * dWf[ij * C + k];
+  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < C * s2; i += gridDim.x * blockDim.x) {
+    int c = i / s2, ij = i - c * s2;
+    db0[i] = w2[c] * dbf[ij];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < C) {
+    int c = threadIdx.x;
+    double a = 0.0;
+    for (int ij = 0; ij < s2; ++ij) {
+      for (int k = 0; k < C; ++k) a += (double)w0[((long long)c * s2 + ij) * C + k] * (double)dWf[ij * C + k];
+      a += (double)b0[c * s2 + ij] * (double)dbf[ij];
+    }
+    dw2[c] = (float)a;
+  }
+}
+
+// xg[p][0..8] = the 9 zero-padded 3x3 neighbours of LR pixel p inside its view (SAI mosaic input), xg[p][9..15] = 0
+__global__ __launch_bounds__(256) void k_init_gather9(const float* __restrict__ x, float* __restrict__ xg, int B, int A, int h, int w) {
+  const long long npix = (long long)B * A * A * h * w;
+  const int Wm = A * w, Hm = A * h;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < npix * 16; g += (long long)gridDim.x * 256) {
+    long long pix = g >> 4;
+    int k = (int)(g & 15);
+    float v = 0.f;
+    if (k < 9) {
+      int xx = (int)(pix % w);
+      long long t = pix / w;
+      int yy = (int)(t % h);
+      t /= h;
+      int view = (int)(t % (A * A));
+      int b = (int)(t / (A * A));
+      int u = view / A, vv = view - u * A;
+      int sy = yy + k / 3 - 1, sx = xx + k % 3 - 1;
+      if (sy >= 0 && sy < h && sx >= 0 && sx < w) v = x[(long long)b * Hm * Wm + (long long)(u * h + sy) * Wm + vv * w + sx];
+    }
+    xg[g] = v;
+  }
+}
+
+// chunked transposed pack for the dgrad of a 1x1 conv followed by a (1-D) pixel shuffle:
+// w (O = r2*ch, C) -> out[q (r2)][k (Cpad32)][c (ch)] = w[nref(q,c)][k],  nref = perm ? c*r2+q : q*ch+c
+__global__ __launch_bounds__(256) void k_pack_chunkT(const float* __restrict__ w, float* __restrict__ out, int O, int C, int ch, int perm, int Cpad) {
+  const int r2 = O / ch;
+  const long long total = (long long)r2 * Cpad * ch;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % ch);
+    long long t = i / ch;
+    int k = (int)(t % Cpad);
+    int q = (int)(t / Cpad);
+    int nref = perm ? c * r2 + q : q * ch + c;
+    out[i] = k < C ? w[(long long)nref * C + k] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_add_inplace(float4* __restrict__ a, const float4* __restrict__ b, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 x = a[i], y = b[i];
+    a[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+}  // namespace
+
+int lfsr_add_inplace(float* a, const float* b, long long n, hipStream_t st) {
+  if (n & 3) return LFSR_E_ARG;
+  unsigned grid = lfsr_blocks(n / 4, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_add_inplace, dim3(grid), dim3(256), 0, st, reinterpret_cast<float4*>(a), reinterpret_cast<const float4*>(b), n / 4);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st) {
+  GemmArgs p{};
+  p.X = g.X; p.x_stride = g.x_stride; p.x_choff = g.x_choff; p.Wp = g.Wp; p.bias = nullptr;
+  p.Y = g.Y; p.y_stride = g.y_stride; p.y_choff = g.y_choff;
+  p.R1 = g.R1; p.r1_stride = g.r1_stride; p.r1_choff = g.r1_choff;
+  p.Mk = g.Mk; p.mk_stride = g.mk_stride; p.mk_choff = g.mk_choff; p.mk_slope = g.mk_slope;
+  p.M = g.M; p.N = g.N; p.Npad = npad32(g.N); p.A = g.A; p.AA = g.A * g.A; p.H = g.h; p.W = g.w; p.ntaps = g.ntaps; p.CH = g.CH; p.slope = 1.0f;
+  if ((g.x_stride | g.x_choff) & 3) return LFSR_E_ARG;
+#define BG(IM, OM, CI, NT) if (g.in_mode == IM && g.out_mode == OM && g.cin == CI && p.Npad % (32 * NT) == 0) return launch_gemm<IM, OM, CI, NT>(p, st);
+  BG(IN_SAME, OUT_SAME, 64, 1)      // fuse.0 dgrad (64 -> 144)
+  BG(IN_ANG, OUT_SAME, 16, 1)       // AngConv.2 dgrad (A*A x 16 -> 16)
+  BG(IN_SAME, OUT_VIEWS, 16, 2)     // AngConv.0 dgrad (16 -> A*A x 64), accumulates into dX
+  BG(IN_CHK_H, OUT_SAME, 32, 1)     // EPIConv.2 dgrad, horizontal
+  BG(IN_CHK_V, OUT_SAME, 32, 1)     //                  vertical
+  BG(IN_LINE_H, OUT_EPIH, 32, 2)    // EPIConv.0 dgrad, horizontal (32 -> A x 64), accumulates into dX
+  BG(IN_LINE_V, OUT_EPIV, 32, 2)    //                  vertical
+  BG(IN_CONV3, OUT_SAME, 64, 2)     // 3x3 dgrad fallback
+#undef BG
+  return LFSR_E_ARG;
+}
+
+int lfsr_conv3x3_bwd_data(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, float* dx, int dx_stride, int dx_choff,
+                          const float* r1, int r1_stride, int r1_choff, const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                          int n_img, int h, int w, hipStream_t st) {
+  const bool al = !((dy_stride | dy_choff | dx_stride | dx_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!mk || !((mk_stride | mk_choff) & 3));
+  if (al)
+    return lfsr_conv3x3_halo_launch(dy, dy_stride, dy_choff, wT_packed, dx, dx_stride, dx_choff, r1, r1_stride, r1_choff, nullptr, 0, 0,
+                                    mk, mk_stride, mk_choff, mk_slope, n_img, h, w, 1.0f, st);
+  LfsrGemm g{};
+  g.in_mode = LFSR_IN_CONV3; g.out_mode = LFSR_OUT_SAME; g.cin = 64;
+  g.X = dy; g.x_stride = dy_stride; g.x_choff = dy_choff; g.Wp = wT_packed; g.Y = dx; g.y_stride = dx_stride; g.y_choff = dx_choff;
+  g.R1 = r1; g.r1_stride = r1_stride; g.r1_choff = r1_choff; g.Mk = mk; g.mk_stride = mk_stride; g.mk_choff = mk_choff; g.mk_slope = mk_slope;
+  g.M = n_img * h * w; g.N = 64; g.A = 1; g.h = h; g.w = w; g.ntaps = 9; g.CH = 64;
+  return lfsr_bwd_gemm(g, st);
+}
+
+int lfsr_head_bwd_data(const float* dout, const float* wf, float* df, float* g16, int B, int A, int h, int w, int s, hipStream_t st) {
+  long long total = (long long)B * A * A * h * w * 16;
+  unsigned grid = lfsr_blocks(total, 256);
+  if (grid > 4096) grid = 4096;
+  switch (s) {
+    case 2: hipLaunchKernelGGL((k_head_bwd<2>), dim3(grid), dim3(256), 0, st, dout, wf, df, g16, B, A, h, w); break;
+    case 3: hipLaunchKernelGGL((k_head_bwd<3>), dim3(grid), dim3(256), 0, st, dout, wf, df, g16, B, A, h, w); break;
+    case 4: hipLaunchKernelGGL((k_head_bwd<4>), dim3(grid), dim3(256), 0, st, dout, wf, df, g16, B, A, h, w); break;
+    default: return LFSR_E_ARG;
+  }
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_colsum(const float* g, int M, int N, float* partial, int* nblk_out, hipStream_t st) {
+  if (N > 16) return LFSR_E_ARG;
+  int rows = 4096;
+  int nblk = (M + rows - 1) / rows;
+  if (nblk_out) *nblk_out = nblk;
+  if (!g) return LFSR_OK;   // size query
+  hipLaunchKernelGGL(k_colsum, dim3(nblk), dim3(256), 0, st, g, M, N, partial, rows);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_head_fold_bwd(const float* dWf, const float* colsum_partial, int nblk, const float* w0, const float* b0, const float* w2,
+                       float* dw0, float* db0, float* dw2, int s, hipStream_t st) {
+  hipLaunchKernelGGL(k_head_fold_bwd, dim3(64), dim3(256), 0, st, dWf, colsum_partial, nblk, w0, b0, w2, dw0, db0, dw2, s * s);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_init_gather9(const float* x, float* xg, int B, int A, int h, int w, hipStream_t st) {
+  long long total = (long long)B * A * A * h * w * 16;
+  unsigned grid = lfsr_blocks(total, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_init_gather9, dim3(grid), dim3(256), 0, st, x, xg, B, A, h, w);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_pack_weight_chunkT(const float* w, float* out, int O, int C, int ch, int perm, hipStream_t st) {
+  if (!w || !out || O <= 0 || C <= 0 || ch <= 0 || O % ch) return LFSR_E_ARG;
+  long long total = (long long)(O / ch) * npad32(C) * ch;
+  hipLaunchKernelGGL(k_pack_chunkT, dim3(lfsr_blocks(total, 256)), dim3(256), 0, st, w, out, O, C, ch, perm, npad32(C));
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

@@ -12,7 +12,7 @@
 // LDS: 340 x 272 B (halo, rows padded to 68 floats -> conflict-free ds_read_b128) + 2 x 64 x 272 B = 124 KB,
 // one block per CU, 2 waves per SIMD.  The epilogue transposes the accumulators through the (then dead)
 // halo region so that stores/residual loads are 16 B per lane, 256 B contiguous per pixel.
-#include "lfsr_common.h"
+#include "lfsr_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -30,6 +30,7 @@ struct ConvArgs {
   float* Y; int y_stride; int y_choff;
   const float* R1; int r1_stride; int r1_choff;
   const float* R2; int r2_stride; int r2_choff;
+  const float* Mk; int mk_stride; int mk_choff; float mk_slope;   // backward: out *= (Mk > 0 ? 1 : mk_slope), before the residual adds
   int n_img, H, W, tiles_y, tiles_x;
   float slope;
 };
@@ -133,11 +134,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         if (tap == 6) { hv[6] = halo_load(6, nimg, ny0, nx0); hv[7] = halo_load(7, nimg, ny0, nx0); hv[8] = halo_load(8, nimg, ny0, nx0); }
         if (tap == 7) { hv[9] = halo_load(9, nimg, ny0, nx0); hv[10] = halo_load(10, nimg, ny0, nx0); }
       }
-      if (tap == 8 && p.R1 && yy < p.H) {   // residual operand of this tile, needed right after the last tap
+      if (tap == 8 && (p.R1 || p.Mk) && yy < p.H) {   // residual (or, in backward, LeakyReLU' mask) operand of this tile
+        const float* src = p.R1 ? p.R1 : p.Mk;
+        const int sst = p.R1 ? p.r1_stride : p.mk_stride, sco = p.R1 ? p.r1_choff : p.mk_choff;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           int pc = (lane >> 4) + 4 * i;
-          res[i] = (x0 + pc < p.W) ? *reinterpret_cast<const float4*>(p.R1 + (row_base + pc) * p.r1_stride + p.r1_choff + (lane & 15) * 4)
+          res[i] = (x0 + pc < p.W) ? *reinterpret_cast<const float4*>(src + (row_base + pc) * sst + sco + (lane & 15) * 4)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -203,6 +206,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         if (x0 + pc < p.W) {
           float4 v = *reinterpret_cast<const float4*>(sO + pc * LROW + ch * 4);
           long long pix = row_base + pc;
+          if (p.Mk) {
+            float4 mk = res[i];
+            if (p.R1) mk = *reinterpret_cast<const float4*>(p.Mk + pix * p.mk_stride + p.mk_choff + ch * 4);
+            v.x *= mk.x > 0.f ? 1.f : p.mk_slope; v.y *= mk.y > 0.f ? 1.f : p.mk_slope;
+            v.z *= mk.z > 0.f ? 1.f : p.mk_slope; v.w *= mk.w > 0.f ? 1.f : p.mk_slope;
+          }
           if (p.R1) { v.x += res[i].x; v.y += res[i].y; v.z += res[i].z; v.w += res[i].w; }
           if (p.R2) {
             float4 r = *reinterpret_cast<const float4*>(p.R2 + pix * p.r2_stride + p.r2_choff + ch * 4);
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
 // internal entry used by lfsr_conv3x3_fwd (gemm_gather.hip)
 int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                             const float* mk, int mk_stride, int mk_choff, float mk_slope,
                              int n_img, int h, int w, float slope, hipStream_t st) {
   static bool attr_set[64] = {};   // per device: the >64 KB dynamic-LDS opt-in is a per-device function attribute
   int dev = 0;
@@ -237,6 +247,7 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed;
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
   p.R1 = r1; p.r1_stride = r1_stride; p.r1_choff = r1_choff; p.R2 = r2; p.r2_stride = r2_stride; p.r2_choff = r2_choff;
+  p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
   p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + TR - 1) / TR; p.tiles_x = (w + TC - 1) / TC; p.slope = slope;
   long long nblk = (long long)n_img * p.tiles_y * p.tiles_x;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;

@@ -5,7 +5,7 @@
 #include <string>
 #include <vector>
 
-#include "lfsr_common.h"
+#include "lfsr_internal.h"
 
 namespace {
 struct Slot {
@@ -14,6 +14,10 @@ struct Slot {
   size_t numel = 0;    // expected raw element count
   int O = 0, C = 0, T = 0, perm = 0, ch = 0;
   bool raw = false, loaded = false;
+  // transposed packing used by the data gradients: 0 none, 1 pack_T flipped (3x3), 2 pack_T, 3 chunkT perm 1 ch 16, 4 chunkT perm 0 ch 32
+  int kindT = 0;
+  size_t offT = 0, floatsT = 0;
+  size_t grad_off = 0;   // offset in the flat gradient bucket (state_dict order)
 };
 inline size_t align64(size_t f) { return (f + 63) / 64 * 64; }  // 256-B granules
 }  // namespace
@@ -21,6 +25,8 @@ inline size_t align64(size_t f) { return (f + 63) / 64 * 64; }  // 256-B granule
 struct lfsr_distgssr {
   int A, s, G, NB, C;
   std::map<std::string, Slot> slots;
+  std::vector<std::string> order;   // state_dict order
+  size_t n_params = 0;
   size_t packed_floats = 0, off_wf = 0, off_bf = 0;
   float* packed = nullptr;
   bool finalized = false;
@@ -35,15 +41,22 @@ struct lfsr_distgssr {
     return e;
   }
 
-  void add(const std::string& k, int O, int Cc, int T, int perm, int ch, bool raw) {
+  void add(const std::string& k, int O, int Cc, int T, int perm, int ch, bool raw, int kindT = 0) {
     Slot sl;
-    sl.O = O; sl.C = Cc; sl.T = T; sl.perm = perm; sl.ch = ch; sl.raw = raw;
+    sl.O = O; sl.C = Cc; sl.T = T; sl.perm = perm; sl.ch = ch; sl.raw = raw; sl.kindT = kindT;
     sl.numel = (size_t)O * Cc * T;
     sl.floats = raw ? sl.numel : lfsr_packed_weight_floats(O, Cc, T);
     sl.off = packed_floats;
     packed_floats += align64(sl.floats);
+    if (kindT == 1 || kindT == 2) sl.floatsT = (size_t)T * ((Cc + 31) / 32 * 32) * O;
+    if (kindT == 3 || kindT == 4) sl.floatsT = (size_t)(O / (kindT == 3 ? 16 : 32)) * ((Cc + 31) / 32 * 32) * (kindT == 3 ? 16 : 32);
+    if (kindT) { sl.offT = packed_floats; packed_floats += align64(sl.floatsT); }
+    sl.grad_off = n_params;
+    n_params += sl.numel;
     slots[k] = sl;
+    order.push_back(k);
   }
+  const float* wT(const std::string& k) const { return packed + slots.at(k).offT; }
   const float* w(const std::string& k) const { return packed + slots.at(k).off; }
 };
 
@@ -58,18 +71,18 @@ int lfsr_distgssr_create(lfsr_distgssr** out, int A, int scale, int n_group, int
   for (int g = 0; g < n_group; ++g) {
     for (int b = 0; b < n_block; ++b) {
       std::string p = "disentg.Group." + std::to_string(g) + ".Block." + std::to_string(b) + ".";
-      c->add(p + "SpaConv.0.weight", 64, 64, 9, 0, 0, false);
-      c->add(p + "SpaConv.2.weight", 64, 64, 9, 0, 0, false);
-      c->add(p + "AngConv.0.weight", 16, 64, AA, 0, 0, false);
-      c->add(p + "AngConv.2.weight", 16 * AA, 16, 1, 1, 16, false);
-      c->add(p + "EPIConv.0.weight", 32, 64, AA, 0, 0, false);
-      c->add(p + "EPIConv.2.weight", 32 * A, 32, 1, 0, 0, false);
-      c->add(p + "fuse.0.weight", 64, 144, 1, 0, 0, false);
-      c->add(p + "fuse.2.weight", 64, 64, 9, 0, 0, false);
+      c->add(p + "SpaConv.0.weight", 64, 64, 9, 0, 0, false, 1);
+      c->add(p + "SpaConv.2.weight", 64, 64, 9, 0, 0, false, 1);
+      c->add(p + "AngConv.0.weight", 16, 64, AA, 0, 0, false, 2);
+      c->add(p + "AngConv.2.weight", 16 * AA, 16, 1, 1, 16, false, 3);
+      c->add(p + "EPIConv.0.weight", 32, 64, AA, 0, 0, false, 2);
+      c->add(p + "EPIConv.2.weight", 32 * A, 32, 1, 0, 0, false, 4);
+      c->add(p + "fuse.0.weight", 64, 144, 1, 0, 0, false, 2);
+      c->add(p + "fuse.2.weight", 64, 64, 9, 0, 0, false, 1);
     }
-    c->add("disentg.Group." + std::to_string(g) + ".conv.weight", 64, 64, 9, 0, 0, false);
+    c->add("disentg.Group." + std::to_string(g) + ".conv.weight", 64, 64, 9, 0, 0, false, 1);
   }
-  c->add("disentg.conv.weight", 64, 64, 9, 0, 0, false);
+  c->add("disentg.conv.weight", 64, 64, 9, 0, 0, false, 1);
   c->add("upsample.0.weight", 64 * scale * scale, 64, 1, 0, 0, true);
   c->add("upsample.0.bias", 64 * scale * scale, 1, 1, 0, 0, true);
   c->add("upsample.2.weight", 1, 64, 1, 0, 0, true);
@@ -133,6 +146,12 @@ int lfsr_distgssr_load_param(lfsr_distgssr* c, const char* key, const float* dat
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
   } else {
     int rc = lfsr_pack_conv_weight(data, c->packed + sl.off, sl.O, sl.C, sl.T, sl.perm, sl.ch, stream);
+    if (rc) return rc;
+    float* tdst = c->packed + sl.offT;
+    if (sl.kindT == 1) rc = lfsr_pack_weight_T(data, tdst, sl.O, sl.C, sl.T, 1, lfsr_stream(stream));
+    if (sl.kindT == 2) rc = lfsr_pack_weight_T(data, tdst, sl.O, sl.C, sl.T, 0, lfsr_stream(stream));
+    if (sl.kindT == 3) rc = lfsr_pack_weight_chunkT(data, tdst, sl.O, sl.C, 16, 1, lfsr_stream(stream));
+    if (sl.kindT == 4) rc = lfsr_pack_weight_chunkT(data, tdst, sl.O, sl.C, 32, 0, lfsr_stream(stream));
     if (rc) return rc;
   }
   sl.loaded = true;
@@ -250,6 +269,258 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
 int lfsr_distgssr_forward(lfsr_distgssr* c, const float* x, float* out, int B, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream) {
   return lfsr_distgssr_forward_taps(c, x, out, B, h, w, workspace, workspace_bytes, nullptr, stream);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// Training: forward that keeps every activation the backward needs, and the backward itself
+// (autograd of model/SR/DistgSSR.py:29-111 as driven by train.py:256-264, fp32).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+struct TrainWs {
+  // saved activations
+  float *F0, *D;
+  std::vector<float*> S1, CAT, A16, EH, EV, FZ, OUT, GOUT;
+  // backward scratch
+  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *G16, *XG9, *P[4], *small;
+  size_t pfloats;
+  size_t total;
+};
+
+size_t max_partial_floats(const lfsr_distgssr* c, int B, int h, int w) {
+  const int A = c->A, AA = A * A;
+  const int npix = B * AA * h * w, nlr = B * h * w, nepi = B * A * h * w;
+  size_t m = 0;
+  auto up = [&](size_t v) { if (v > m) m = v; };
+  up(lfsr_wgrad_partial_floats(npix, 9, 64, 64));
+  up(lfsr_wgrad_partial_floats(npix, 1, 64, 144));
+  up(lfsr_wgrad_partial_floats(nlr, AA, 16, 64));
+  up(lfsr_wgrad_partial_floats(nlr, AA, 16, 16));
+  up(lfsr_wgrad_partial_floats(nepi, AA, 32, 64));
+  up(lfsr_wgrad_partial_floats(nepi, A, 32, 32));
+  up(lfsr_wgrad_partial_floats(npix, 1, 16, 64));
+  up(lfsr_wgrad_partial_floats(npix, 1, 64, 16));
+  return m;
+}
+
+void train_layout(const lfsr_distgssr* c, int B, int h, int w, float* base, TrainWs& t) {
+  const int A = c->A, AA = A * A, nb = c->G * c->NB;
+  const size_t npix = (size_t)B * AA * h * w, nlr = (size_t)B * h * w, nepi = (size_t)B * A * h * w;
+  size_t o = 0;
+  auto take = [&](size_t floats) { float* p = base ? base + o : nullptr; o += align64(floats); return p; };
+  t.F0 = take(npix * 64); t.D = take(npix * 64);
+  t.S1.resize(nb); t.CAT.resize(nb); t.A16.resize(nb); t.EH.resize(nb); t.EV.resize(nb); t.FZ.resize(nb); t.OUT.resize(nb); t.GOUT.resize(c->G);
+  for (int i = 0; i < nb; ++i) {
+    t.S1[i] = take(npix * 64); t.CAT[i] = take(npix * 144); t.A16[i] = take(nlr * 16);
+    t.EH[i] = take(nepi * 32); t.EV[i] = take(nepi * 32); t.FZ[i] = take(npix * 64); t.OUT[i] = take(npix * 64);
+  }
+  for (int g = 0; g < c->G; ++g) t.GOUT[g] = take(npix * 64);
+  for (int i = 0; i < 4; ++i) t.g[i] = take(npix * 64);
+  t.dF = take(npix * 64); t.dS1 = take(npix * 64); t.dCAT = take(npix * 144);
+  t.dA16 = take(nlr * 16); t.dE32 = take(nepi * 32); t.G16 = take(npix * 16); t.XG9 = take(npix * 16);
+  t.pfloats = max_partial_floats(c, B, h, w);
+  for (int i = 0; i < 4; ++i) t.P[i] = take(t.pfloats);
+  t.small = take(64 * 1024);
+  t.total = o;
+}
+}  // namespace
+
+extern "C" {
+
+size_t lfsr_distgssr_num_params(const lfsr_distgssr* c) { return c ? c->n_params : 0; }
+
+int lfsr_distgssr_param_offset(const lfsr_distgssr* c, const char* key, size_t* off, size_t* numel) {
+  if (!c || !key) return LFSR_E_ARG;
+  auto it = c->slots.find(key);
+  if (it == c->slots.end()) return LFSR_E_ARG;
+  if (off) *off = it->second.grad_off;
+  if (numel) *numel = it->second.numel;
+  return LFSR_OK;
+}
+
+size_t lfsr_distgssr_train_workspace_bytes(const lfsr_distgssr* c, int B, int h, int w) {
+  if (!c || B <= 0 || h <= 0 || w <= 0) return 0;
+  TrainWs t;
+  train_layout(c, B, h, w, nullptr, t);
+  return t.total * sizeof(float);
+}
+
+int lfsr_distgssr_forward_train(lfsr_distgssr* c, const float* x, float* out, int B, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!c || !x || !out || !workspace || B <= 0 || h <= 0 || w <= 0 || !c->finalized || ((uintptr_t)workspace & 15)) return LFSR_E_ARG;
+  TrainWs t;
+  train_layout(c, B, h, w, (float*)workspace, t);
+  if (workspace_bytes < t.total * sizeof(float)) return LFSR_E_WS;
+  if ((long long)B * c->A * c->A * h * w >= (1LL << 31) / 144) return LFSR_E_ARG;
+  const int A = c->A, AA = A * A, nimg = B * AA;
+  const float L = 0.1f;
+  hipStream_t st = lfsr_stream(stream);
+  int rc;
+#define RC(call) do { rc = (call); if (rc) return rc; } while (0)
+  auto conv = [&](const float* in, const std::string& key, float* o, int ostride, const float* res, float slope) -> int {
+    return lfsr_conv3x3_fwd(in, 64, 0, c->w(key), o, ostride, 0, res, 64, 0, nullptr, 0, 0, nimg, h, w, slope, stream);
+  };
+  RC(lfsr_initconv_fwd(x, c->w("init_conv.weight"), t.F0, 64, 0, B, A, h, w, stream));
+  const float* cur = t.F0;
+  for (int g = 0; g < c->G; ++g) {
+    const float* gin = cur;
+    for (int b = 0; b < c->NB; ++b) {
+      const int i = g * c->NB + b;
+      std::string p = "disentg.Group." + std::to_string(g) + ".Block." + std::to_string(b) + ".";
+      RC(conv(cur, p + "SpaConv.0.weight", t.S1[i], 64, nullptr, L));
+      RC(conv(t.S1[i], p + "SpaConv.2.weight", t.CAT[i], 144, nullptr, L));
+      RC(lfsr_angconv_fwd(cur, 64, 0, c->w(p + "AngConv.0.weight"), c->w(p + "AngConv.2.weight"), t.A16[i], t.CAT[i], 144, 64, B, A, h, w, L, stream));
+      if (lfsr_epi_fused_ok(A, h, w)) {
+        RC(lfsr_epi_fused_launch(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), t.CAT[i], 144, 80, 112, t.EH[i], t.EV[i], B, A, h, w, 3, L, st));
+      } else {
+        RC(lfsr_epiconv_gather(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), t.EH[i], t.CAT[i], 144, 80, B, A, h, w, 0, L, st));
+        RC(lfsr_epiconv_gather(cur, 64, 0, c->w(p + "EPIConv.0.weight"), c->w(p + "EPIConv.2.weight"), t.EV[i], t.CAT[i], 144, 112, B, A, h, w, 1, L, st));
+      }
+      RC(lfsr_pointwise_fwd(t.CAT[i], 144, 0, 144, c->w(p + "fuse.0.weight"), nullptr, t.FZ[i], 64, 0, nimg * h * w, 64, L, stream));
+      RC(conv(t.FZ[i], p + "fuse.2.weight", t.OUT[i], 64, cur, 1.0f));
+      cur = t.OUT[i];
+    }
+    RC(conv(cur, "disentg.Group." + std::to_string(g) + ".conv.weight", t.GOUT[g], 64, gin, 1.0f));
+    cur = t.GOUT[g];
+  }
+  RC(conv(cur, "disentg.conv.weight", t.D, 64, t.F0, 1.0f));
+  RC(lfsr_upsample_head_fwd(t.D, 64, 0, c->packed + c->off_wf, c->packed + c->off_bf, x, out, B, A, h, w, c->s, stream));
+#undef RC
+  return LFSR_OK;
+}
+
+int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, int B, int h, int w, void* workspace, size_t workspace_bytes,
+                           float* grads, size_t n_grads, void* stream) {
+  if (!c || !x || !dout || !workspace || !grads || B <= 0 || h <= 0 || w <= 0 || !c->finalized || n_grads != c->n_params) return LFSR_E_ARG;
+  TrainWs t;
+  train_layout(c, B, h, w, (float*)workspace, t);
+  if (workspace_bytes < t.total * sizeof(float)) return LFSR_E_WS;
+  const int A = c->A, AA = A * A, nimg = B * AA;
+  const int npix = nimg * h * w, nlr = B * h * w, nepi = B * A * h * w;
+  const float L = 0.1f;
+  hipStream_t st = lfsr_stream(stream);
+  int rc;
+#define RC(call) do { rc = (call); if (rc) return rc; } while (0)
+  auto G = [&](const std::string& k) -> float* { return grads + c->slots.at(k).grad_off; };
+  // weight gradient of a 3x3 conv: dW[tap][n][k] = sum_m g[m][n] * xin[conv3 src(m,tap)][k]
+  auto wgrad3 = [&](const std::string& key, const float* xin, const float* g, int g_stride) -> int {
+    int r = lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_CONV3, g, g_stride, 0, xin, 64, 0, t.P[0], npix, 64, 64, 1, h, w, 9, st);
+    if (r) return r;
+    return lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 9, 64), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, st);
+  };
+  auto dgrad3 = [&](const float* dy, int dy_stride, const std::string& key, float* dx, const float* r1, const float* r2_unused, const float* mk, int mk_stride) -> int {
+    (void)r2_unused;
+    return lfsr_conv3x3_bwd_data(dy, dy_stride, 0, c->wT(key), dx, 64, 0, r1, 64, 0, mk, mk_stride, 0, L, nimg, h, w, st);
+  };
+  auto pick = [&](const float* a, const float* b, const float* d) -> float* {
+    for (int i = 0; i < 4; ++i)
+      if (t.g[i] != a && t.g[i] != b && t.g[i] != d) return t.g[i];
+    return nullptr;
+  };
+
+  // ---- head: out = PS(Wf f + bf) + bilinear(x) ---------------------------------------------------------------
+  float* dD = t.g[0];
+  RC(lfsr_head_bwd_data(dout, c->packed + c->off_wf, dD, t.G16, B, A, h, w, c->s, st));
+  {
+    float* dWf = t.small;                 // (s*s, 64), rows >= s*s unused
+    float* colp = t.small + 16 * 64;      // column-sum partials
+    RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.G16, 16, 0, t.D, 64, 0, t.P[0], npix, 16, 64, 1, h, w, 1, st));
+    RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 1, 64), nullptr, 0, dWf, 16, 64, 1, 0, 0, 0, 0, 0, st));
+    int nblk = 0;
+    RC(lfsr_colsum(t.G16, npix, 16, colp, &nblk, st));
+    if ((size_t)(16 * 64 + nblk * 16) > 64 * 1024) return LFSR_E_WS;
+    RC(lfsr_head_fold_bwd(dWf, colp, nblk, c->w("upsample.0.weight"), c->w("upsample.0.bias"), c->w("upsample.2.weight"),
+                          G("upsample.0.weight"), G("upsample.0.bias"), G("upsample.2.weight"), c->s, st));
+  }
+  // ---- cascade conv: D = conv(GOUT[last]) + F0 ----------------------------------------------------------------
+  const float* last = t.GOUT[c->G - 1];
+  RC(wgrad3("disentg.conv.weight", last, dD, 64));
+  float* gcur = pick(dD, nullptr, nullptr);
+  RC(dgrad3(dD, 64, "disentg.conv.weight", gcur, nullptr, nullptr, nullptr, 0));
+  // ---- groups, reversed ----------------------------------------------------------------------------------------
+  for (int g = c->G - 1; g >= 0; --g) {
+    float* dG = gcur;   // gradient at the group's output; also flows through the group skip to its input
+    const float* blk_last = t.OUT[g * c->NB + c->NB - 1];
+    std::string gk = "disentg.Group." + std::to_string(g) + ".conv.weight";
+    RC(wgrad3(gk, blk_last, dG, 64));
+    float* gy = pick(dD, dG, nullptr);
+    RC(dgrad3(dG, 64, gk, gy, nullptr, nullptr, nullptr, 0));
+    for (int b = c->NB - 1; b >= 0; --b) {
+      const int i = g * c->NB + b;
+      std::string p = "disentg.Group." + std::to_string(g) + ".Block." + std::to_string(b) + ".";
+      const float* Xin = b > 0 ? t.OUT[i - 1] : (g > 0 ? t.GOUT[g - 1] : t.F0);
+      float* gx = pick(dD, dG, gy);
+      // fuse.2 : OUT = conv(FZ) + Xin
+      RC(wgrad3(p + "fuse.2.weight", t.FZ[i], gy, 64));
+      RC(dgrad3(gy, 64, p + "fuse.2.weight", t.dF, nullptr, nullptr, t.FZ[i], 64));
+      // fuse.0 : FZ = lrelu(1x1(CAT))
+      RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.dF, 64, 0, t.CAT[i], 144, 0, t.P[0], npix, 64, 144, 1, h, w, 1, st));
+      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 1, 144), nullptr, 0, G(p + "fuse.0.weight"), 64, 144, 1, 0, 0, 0, 0, 0, st));
+      {
+        LfsrGemm q{};
+        q.in_mode = LFSR_IN_SAME; q.out_mode = LFSR_OUT_SAME; q.cin = 64; q.X = t.dF; q.x_stride = 64; q.Wp = c->wT(p + "fuse.0.weight");
+        q.Y = t.dCAT; q.y_stride = 144; q.Mk = t.CAT[i]; q.mk_stride = 144; q.mk_slope = L;
+        q.M = npix; q.N = 144; q.A = 1; q.h = 1; q.w = 1; q.ntaps = 1; q.CH = 144;
+        RC(lfsr_bwd_gemm(q, st));
+      }
+      // SpaConv : CAT[0:64] = lrelu(conv(S1)), S1 = lrelu(conv(Xin))
+      RC(wgrad3(p + "SpaConv.2.weight", t.S1[i], t.dCAT, 144));
+      RC(dgrad3(t.dCAT, 144, p + "SpaConv.2.weight", t.dS1, nullptr, nullptr, t.S1[i], 64));
+      RC(wgrad3(p + "SpaConv.0.weight", Xin, t.dS1, 64));
+      RC(dgrad3(t.dS1, 64, p + "SpaConv.0.weight", gx, gy, nullptr, nullptr, 0));          // gx = gy (block skip) + dSpa
+      // AngConv : CAT[64:80] = PS(lrelu(1x1(A16))), A16 = lrelu(convAxA(Xin))
+      RC(lfsr_wgrad_launch(LFSR_IN_ANG, LFSR_IN_SAME, t.dCAT, 144, 64, t.A16[i], 16, 0, t.P[0], nlr, 16, 16, A, h, w, AA, st));
+      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nlr, AA, 16), nullptr, 0, G(p + "AngConv.2.weight"), 16 * AA, 16, AA, 1, 16, 0, 0, 1, st));
+      {
+        LfsrGemm q{};
+        q.in_mode = LFSR_IN_ANG; q.out_mode = LFSR_OUT_SAME; q.cin = 16; q.X = t.dCAT; q.x_stride = 144; q.x_choff = 64; q.Wp = c->wT(p + "AngConv.2.weight");
+        q.Y = t.dA16; q.y_stride = 16; q.Mk = t.A16[i]; q.mk_stride = 16; q.mk_slope = L;
+        q.M = nlr; q.N = 16; q.A = A; q.h = h; q.w = w; q.ntaps = AA; q.CH = 16;
+        RC(lfsr_bwd_gemm(q, st));
+      }
+      RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_ANG, t.dA16, 16, 0, Xin, 64, 0, t.P[0], nlr, 16, 64, A, h, w, AA, st));
+      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nlr, AA, 64), nullptr, 0, G(p + "AngConv.0.weight"), 16, 64, AA, 0, 0, 0, 0, 0, st));
+      {
+        LfsrGemm q{};
+        q.in_mode = LFSR_IN_SAME; q.out_mode = LFSR_OUT_VIEWS; q.cin = 16; q.X = t.dA16; q.x_stride = 16; q.Wp = c->wT(p + "AngConv.0.weight");
+        q.Y = gx; q.y_stride = 64; q.R1 = gx; q.r1_stride = 64;
+        q.M = nlr; q.N = AA * 64; q.A = A; q.h = h; q.w = w; q.ntaps = 1; q.CH = 64;
+        RC(lfsr_bwd_gemm(q, st));
+      }
+      // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)
+      for (int vert = 0; vert < 2; ++vert) {
+        const float* E = vert ? t.EV[i] : t.EH[i];
+        const int choff = vert ? 112 : 80;
+        float* Pa = t.P[vert ? 2 : 0];   // EPIConv.2 partials
+        float* Pb = t.P[vert ? 3 : 1];   // EPIConv.0 partials
+        RC(lfsr_wgrad_launch(vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H, LFSR_IN_SAME, t.dCAT, 144, choff, E, 32, 0, Pa, nepi, 32, 32, A, h, w, A, st));
+        LfsrGemm q{};
+        q.in_mode = vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H; q.out_mode = LFSR_OUT_SAME; q.cin = 32; q.X = t.dCAT; q.x_stride = 144; q.x_choff = choff;
+        q.Wp = c->wT(p + "EPIConv.2.weight"); q.Y = t.dE32; q.y_stride = 32; q.Mk = E; q.mk_stride = 32; q.mk_slope = L;
+        q.M = nepi; q.N = 32; q.A = A; q.h = h; q.w = w; q.ntaps = A; q.CH = 32;
+        RC(lfsr_bwd_gemm(q, st));
+        RC(lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, t.dE32, 32, 0, Xin, 64, 0, Pb, nepi, 32, 64, A, h, w, AA, st));
+        LfsrGemm r{};
+        r.in_mode = vert ? LFSR_IN_LINE_V : LFSR_IN_LINE_H; r.out_mode = vert ? LFSR_OUT_EPIV : LFSR_OUT_EPIH; r.cin = 32; r.X = t.dE32; r.x_stride = 32;
+        r.Wp = c->wT(p + "EPIConv.0.weight"); r.Y = gx; r.y_stride = 64; r.R1 = gx; r.r1_stride = 64;
+        r.M = nepi; r.N = A * 64; r.A = A; r.h = h; r.w = w; r.ntaps = A; r.CH = 64;
+        RC(lfsr_bwd_gemm(r, st));
+      }
+      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nepi, A, 32), t.P[2], lfsr_wgrad_splits(nepi, A, 32), G(p + "EPIConv.2.weight"), 32 * A, 32, A, 0, 32, 0, 0, 1, st));
+      RC(lfsr_wgrad_reduce(t.P[1], lfsr_wgrad_splits(nepi, AA, 64), t.P[3], lfsr_wgrad_splits(nepi, AA, 64), G(p + "EPIConv.0.weight"), 32, 64, AA, 0, 0, 0, 0, 0, st));
+      gy = gx;
+    }
+    // group skip: grad at the group's input = (through the blocks) + dG
+    RC(lfsr_add_inplace(gy, dG, (long long)npix * 64, st));
+    gcur = gy;
+  }
+  // ---- init_conv: F0 = conv(x) ; dF0 = (through the groups) + dD (cascade skip) -------------------------------
+  RC(lfsr_add_inplace(gcur, dD, (long long)npix * 64, st));
+  RC(lfsr_init_gather9(x, t.XG9, B, A, h, w, st));
+  RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, gcur, 64, 0, t.XG9, 16, 0, t.P[0], npix, 64, 16, 1, h, w, 1, st));
+  RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 1, 16), nullptr, 0, G("init_conv.weight"), 64, 16, 1, 0, 0, 0, 9, 0, st));
+#undef RC
+  return LFSR_OK;
 }
 
 }  // extern "C"

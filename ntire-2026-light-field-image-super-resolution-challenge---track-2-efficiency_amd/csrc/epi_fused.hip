@@ -12,7 +12,7 @@
 // next stage prefetched into registers while the current one computes.  After the last stage the 32x32 result
 // tile is LeakyReLU'd, transposed through LDS into MFMA A-operand order and multiplied by the 1x1 weights
 // (20 KB, read straight from L1/L2), then scattered by chunk (= PixelShuffle1D) to the A views.
-#include "lfsr_common.h"
+#include "lfsr_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -25,6 +25,7 @@ struct EpiArgs {
   const float* W1;    // [A*A][32][64]  (tap k, n, c)
   const float* W2;    // [32A][32]      (n = chunk*32 + c, k): the 1x1 weights, row-major as packed by lfsr_pack_conv_weight
   float* Y; int y_stride; int choffH; int choffV;
+  float* TH; float* TV;   // optional (lines*len, 32): post-LeakyReLU stage-1 activations saved for backward
   int B, A, H, W;
   int tilesH, tilesV;   // tiles per pass; blockIdx.x < tilesH -> horizontal
   float slope;
@@ -133,7 +134,16 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
   for (int r = 0; r < 16; ++r) {
     int pos = (r & 3) + 8 * (r >> 2) + 4 * half;
     float v = acc[r];
-    sT[pos * TROW + l31] = v >= 0.f ? v : v * p.slope;
+    v = v >= 0.f ? v : v * p.slope;
+    sT[pos * TROW + l31] = v;
+    float* tsave = vert ? p.TV : p.TH;
+    // rows of the saved matrix are ordered like the gather-GEMM's stage-1 rows: (b*A+u, y, x) / (b*A+v, y, x)
+    if (tsave && sLine[wave] >= 0 && pos < len) {
+      int ln = tile * LINES + wave;
+      int q = ln / across, o = ln - q * across;
+      long long row = vert ? ((long long)q * p.H + pos) * p.W + o : ((long long)q * p.H + o) * p.W + pos;
+      tsave[row * 32 + l31] = v;
+    }
   }
   __builtin_amdgcn_wave_barrier();
   float4 fa[4];
@@ -179,7 +189,7 @@ bool lfsr_epi_fused_ok(int A, int h, int w) {
 }
 
 int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,
-                          int choffH, int choffV, int B, int A, int h, int w, int which, float slope, hipStream_t st) {
+                          int choffH, int choffV, float* t_h, float* t_v, int B, int A, int h, int w, int which, float slope, hipStream_t st) {
   // which: 1 = horizontal only, 2 = vertical only, 3 = both
   if (!lfsr_epi_fused_ok(A, h, w)) return LFSR_E_ARG;
   static bool attr_set[64] = {};
@@ -193,7 +203,7 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   }
   EpiArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.W1 = w1_packed; p.W2 = w2_packed;
-  p.Y = y; p.y_stride = y_stride; p.choffH = choffH; p.choffV = choffV;
+  p.Y = y; p.y_stride = y_stride; p.choffH = choffH; p.choffV = choffV; p.TH = t_h; p.TV = t_v;
   p.B = B; p.A = A; p.H = h; p.W = w; p.slope = slope;
   p.tilesH = (which & 1) ? (B * A * h + LINES - 1) / LINES : 0;
   p.tilesV = (which & 2) ? (B * A * w + LINES - 1) / LINES : 0;

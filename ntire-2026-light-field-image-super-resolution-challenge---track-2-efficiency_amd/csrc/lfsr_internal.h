@@ -1,0 +1,55 @@
+// Internal (non-ABI) entry points shared between the translation units of liblfsr_hip.so.
+#pragma once
+#include "lfsr_common.h"
+
+// gather modes (values match gemm_gather_kernel.h)
+enum { LFSR_IN_SAME = 0, LFSR_IN_CONV3 = 1, LFSR_IN_ANG = 2, LFSR_IN_EPIH = 3, LFSR_IN_EPIV = 4,
+       LFSR_IN_CHK_H = 5, LFSR_IN_CHK_V = 6, LFSR_IN_LINE_H = 7, LFSR_IN_LINE_V = 8 };
+enum { LFSR_OUT_SAME = 0, LFSR_OUT_VIEWS = 1, LFSR_OUT_EPIH = 2, LFSR_OUT_EPIV = 3 };
+
+// conv3x3_halo.hip
+int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
+                             const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                             const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                             int n_img, int h, int w, float slope, hipStream_t st);
+// epi_fused.hip  (t_h / t_v: optional (B*A*h*w, 32) buffers receiving the post-LeakyReLU stage-1 activations for backward)
+bool lfsr_epi_fused_ok(int A, int h, int w);
+int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,
+                          int choffH, int choffV, float* t_h, float* t_v, int B, int A, int h, int w, int which, float slope, hipStream_t st);
+
+// gemm_gather.hip: two-launch gather-GEMM EPI path; tmp (B*A*h*w, 32) receives the stage-1 activations
+extern "C" int lfsr_epiconv_gather(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                        float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical, float slope, hipStream_t st);
+
+// bwd_ops.hip: one entry for every backward gather-GEMM (dgrad) instantiation
+struct LfsrGemm {
+  int in_mode, out_mode, cin;
+  const float* X; int x_stride, x_choff;
+  const float* Wp;
+  float* Y; int y_stride, y_choff;
+  const float* R1; int r1_stride, r1_choff;        // added after the mask (may alias Y: in-place accumulate)
+  const float* Mk; int mk_stride, mk_choff; float mk_slope;
+  int M, N, A, h, w, ntaps, CH;
+};
+int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st);
+int lfsr_conv3x3_bwd_data(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, float* dx, int dx_stride, int dx_choff,
+                          const float* r1, int r1_stride, int r1_choff, const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                          int n_img, int h, int w, hipStream_t st);
+int lfsr_head_bwd_data(const float* dout, const float* wf, float* df, float* g16, int B, int A, int h, int w, int s, hipStream_t st);
+int lfsr_colsum(const float* g, int M, int N, float* partial, int* nblk_out, hipStream_t st);
+int lfsr_head_fold_bwd(const float* dWf, const float* colsum_partial, int nblk, const float* w0, const float* b0, const float* w2,
+                       float* dw0, float* db0, float* dw2, int s, hipStream_t st);
+int lfsr_init_gather9(const float* x, float* xg, int B, int A, int h, int w, hipStream_t st);
+int lfsr_add_inplace(float* a, const float* b, long long n, hipStream_t st);   // a += b
+int lfsr_pack_weight_chunkT(const float* w, float* out, int O, int C, int ch, int perm, hipStream_t st);
+
+// wgrad.hip
+int lfsr_wgrad_splits(int M, int ntaps, int K);
+size_t lfsr_wgrad_partial_floats(int M, int ntaps, int N, int K);
+int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff,
+                      float* P, int M, int N, int K, int A, int h, int w, int ntaps, hipStream_t st);
+// c_valid < C: only the first c_valid input channels are written, with row length c_valid (init_conv's 9 taps)
+int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, float* dW, int O, int C, int T, int perm, int ch,
+                      int accumulate, int c_valid, int chunk_mode, hipStream_t st);
+// chunk_mode = 1: the T 'taps' of the partials are the chunks of a (1-D) pixel shuffle: row = perm ? n*T + t : t*ch + n (n < ch), dW (T*ch, C)
+int lfsr_pack_weight_T(const float* w, float* out, int O, int C, int T, int flip, hipStream_t st);

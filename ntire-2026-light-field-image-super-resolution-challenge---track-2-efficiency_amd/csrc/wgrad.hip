@@ -1,0 +1,207 @@
+// Weight gradients of the gather-GEMM operator family (backward of model/SR/DistgSSR.py:78-111, i.e. what
+// autograd computes for every nn.Conv2d weight at train.py:264), fp32 MFMA:
+//
+//     dW[tap][n][k] = sum_m  G[gsrc(m,tap)][n] * X[xsrc(m,tap)][k]
+//
+// G = gradient rows (N <= 64 channels), X = saved forward input rows (K channels), both gathered with the same
+// index maps as the forward (gemm_gather_kernel.h).  The reduction runs over ALL rows m, so the grid is
+// (row splits, taps, 64-wide k tiles): each 256-thread block reduces its row range for one tap into a 64x64
+// accumulator tile (4 waves = 2x2 quadrants of 32x32, "m" is the MFMA's K dimension, two rows per
+// v_mfma_f32_32x32x2_f32), and writes a PARTIAL [Npad][K] slab.  A second, deterministic pass sums the slabs in
+// split order and scatters into the PyTorch (O, C, kh, kw) layout (no float atomics: bitwise reproducible).
+#include "gemm_gather_kernel.h"
+
+namespace {
+
+constexpr int WG_ROWS = 64;   // rows staged per step
+
+struct WgradArgs {
+  const float* G; int g_stride; int g_choff;
+  const float* X; int x_stride; int x_choff;
+  float* P;                 // partials [nsplit][ntaps][Npad][K]
+  int M, N, Npad, K;
+  int A, AA, H, W, ntaps;
+  int rows_per_split, nsplit;
+};
+
+template <int GIN, int XIN>
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float sG[WG_ROWS * LDS_ROW];
+  __shared__ __attribute__((aligned(16))) float sX[WG_ROWS * LDS_ROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = tid & 15, r0 = tid >> 4;          // 16 threads per row, 16 rows per pass, 4 passes
+  const int split = blockIdx.x, tap = blockIdx.y, k0 = blockIdx.z * 64;
+  const int nq = wave >> 1, kq = wave & 1;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  GemmArgs ga{};   // index maps only
+  ga.M = p.M; ga.A = p.A; ga.AA = p.AA; ga.H = p.H; ga.W = p.W;
+
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  float4 rg[4], rx[4];
+  auto prefetch = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int m = m0 + r0 + 16 * i;
+      rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < m_end) {
+        if (c16 * 4 < p.Npad && c16 * 4 < p.N) {   // N is a multiple of 4 (16/32/64)
+          RowInfo<GIN> ri = decode_row<GIN>(m, ga);
+          int sp = src_pixel<GIN>(ri, tap, ga);
+          if (sp >= 0) rg[i] = *reinterpret_cast<const float4*>(p.G + (long long)sp * p.g_stride + p.g_choff + c16 * 4);
+        }
+        if (k0 + c16 * 4 < p.K) {
+          RowInfo<XIN> ri = decode_row<XIN>(m, ga);
+          int sp = src_pixel<XIN>(ri, tap, ga);
+          if (sp >= 0) rx[i] = *reinterpret_cast<const float4*>(p.X + (long long)sp * p.x_stride + p.x_choff + k0 + c16 * 4);
+        }
+      }
+    }
+  };
+
+  const bool active = nq * 32 < p.Npad && k0 + kq * 32 < p.K;
+  prefetch(m_begin);
+  for (int m0 = m_begin; m0 < m_end; m0 += WG_ROWS) {
+    if (m0 > m_begin) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(sG + (r0 + 16 * i) * LDS_ROW + c16 * 4) = rg[i];
+      *reinterpret_cast<float4*>(sX + (r0 + 16 * i) * LDS_ROW + c16 * 4) = rx[i];
+    }
+    __syncthreads();
+    if (m0 + WG_ROWS < m_end) prefetch(m0 + WG_ROWS);
+    if (active) {
+      const float* gp = sG + half * LDS_ROW + nq * 32 + l31;
+      const float* xp = sX + half * LDS_ROW + kq * 32 + l31;
+#pragma unroll 8
+      for (int mm = 0; mm < WG_ROWS; mm += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[mm * LDS_ROW], xp[mm * LDS_ROW], acc, 0, 0, 0);
+    }
+  }
+  if (active) {
+    // D[row = n][col = k]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half
+    float* out = p.P + (((long long)split * p.ntaps + tap) * p.Npad) * p.K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int n = nq * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      int k = k0 + kq * 32 + l31;
+      if (n < p.Npad && k < p.K) out[(long long)n * p.K + k] = acc[r];
+    }
+  }
+}
+
+// sum partial slabs in split order and scatter to the PyTorch layout (O, C, T): inverse of k_pack_weight.
+// P2 (optional) is a second partial set with the same geometry (the vertical EPI pass shares its weights).
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ P, int nsplit, const float* __restrict__ P2, int nsplit2,
+                                                      float* __restrict__ dW, int O, int C, int T, int Npad, int perm, int ch, int accumulate, int c_valid, int chunk_mode) {
+  const long long total = (long long)T * Npad * C;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int c = (int)(i % C);
+  long long t2 = i / C;
+  int n = (int)(t2 % Npad);
+  int t = (int)(t2 / Npad);
+  if (c >= c_valid) return;
+  if (chunk_mode ? n >= ch : n >= O) return;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += P[(long long)sp * total + i];
+  for (int sp = 0; sp < nsplit2; ++sp) s += P2[(long long)sp * total + i];
+  int nref = n;
+  if (perm == 1) { int r2 = O / ch; int q = n / ch, cc = n - q * ch; nref = cc * r2 + q; }
+  long long o = ((long long)nref * c_valid + c) * T + t;
+  if (chunk_mode) o = (long long)(perm ? n * T + t : t * ch + n) * C + c;
+  dW[o] = accumulate ? dW[o] + s : s;
+}
+
+// transposed pack for dgrad: out[t'][k(Cpad rows)][n] = w[n][k][t]  with t' = flip ? T-1-t : t
+//   (O,C,T) -> [T][Cpad32][O]: the dgrad GEMM contracts over the forward's output channels.
+__global__ __launch_bounds__(256) void k_pack_weight_T(const float* __restrict__ w, float* __restrict__ out, int O, int C, int T, int Cpad, int flip) {
+  const long long total = (long long)T * Cpad * O;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int n = (int)(i % O);
+    long long t2 = i / O;
+    int k = (int)(t2 % Cpad);
+    int tp = (int)(t2 / Cpad);
+    int t = flip ? T - 1 - tp : tp;
+    out[i] = k < C ? w[((long long)n * C + k) * T + t] : 0.f;
+  }
+}
+
+template <int GIN, int XIN>
+int launch_wgrad(WgradArgs p, hipStream_t st) {
+  dim3 grid((unsigned)p.nsplit, (unsigned)p.ntaps, (unsigned)((p.K + 63) / 64));
+  hipLaunchKernelGGL((k_wgrad<GIN, XIN>), grid, dim3(256), 0, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+}  // namespace
+
+// ---- internal API (lfsr_internal.h) -------------------------------------------------------------------------
+#include "lfsr_internal.h"
+
+int lfsr_wgrad_splits(int M, int ntaps, int K) {
+  // aim at ~1500 blocks, >= 256 rows per block
+  long long ktiles = (K + 63) / 64;
+  long long want = 1536 / ((long long)ntaps * ktiles);
+  if (want < 1) want = 1;
+  long long rows = (M + want - 1) / want;
+  if (rows < 256) rows = 256;
+  rows = (rows + WG_ROWS - 1) / WG_ROWS * WG_ROWS;
+  return (int)((M + rows - 1) / rows);
+}
+
+size_t lfsr_wgrad_partial_floats(int M, int ntaps, int N, int K) {
+  return (size_t)lfsr_wgrad_splits(M, ntaps, K) * ntaps * npad32(N) * K;
+}
+
+int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff,
+                      float* P, int M, int N, int K, int A, int h, int w, int ntaps, hipStream_t st) {
+  if (!G || !X || !P || M <= 0 || N <= 0 || N > 64 || (N & 3) || K <= 0 || (K & 3) || ntaps <= 0) return LFSR_E_ARG;
+  if ((g_stride | g_choff | x_stride | x_choff) & 3) return LFSR_E_ARG;
+  WgradArgs p{};
+  p.G = G; p.g_stride = g_stride; p.g_choff = g_choff; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P;
+  p.M = M; p.N = N; p.Npad = npad32(N); p.K = K; p.A = A; p.AA = A * A; p.H = h; p.W = w; p.ntaps = ntaps;
+  p.nsplit = lfsr_wgrad_splits(M, ntaps, K);
+  long long rows = ((long long)M + p.nsplit - 1) / p.nsplit;
+  p.rows_per_split = (int)((rows + WG_ROWS - 1) / WG_ROWS * WG_ROWS);
+#define WG(GM, XM) if (gmode == GM && xmode == XM) return launch_wgrad<GM, XM>(p, st);
+  WG(IN_SAME, IN_CONV3)   // conv3x3
+  WG(IN_SAME, IN_SAME)    // 1x1
+  WG(IN_SAME, IN_ANG)     // AngConv.0
+  WG(IN_ANG, IN_SAME)     // AngConv.2   (G gathered from the A*A views)
+  WG(IN_SAME, IN_EPIH)    // EPIConv.0 horizontal
+  WG(IN_SAME, IN_EPIV)    // EPIConv.0 vertical
+  WG(IN_CHK_H, IN_SAME)   // EPIConv.2 horizontal
+  WG(IN_CHK_V, IN_SAME)   // EPIConv.2 vertical
+#undef WG
+  return LFSR_E_ARG;
+}
+
+int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, float* dW, int O, int C, int T, int perm, int ch,
+                      int accumulate, int c_valid, int chunk_mode, hipStream_t st) {
+  if (c_valid <= 0 || c_valid > C) c_valid = C;
+  if (!P || !dW || O <= 0 || C <= 0 || T <= 0) return LFSR_E_ARG;
+  const int Npad = chunk_mode ? npad32(ch) : npad32(O);
+  long long total = (long long)T * Npad * C;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(lfsr_blocks(total, 256)), dim3(256), 0, st, P, nsplit, P2, P2 ? nsplit2 : 0, dW, O, C, T, Npad, perm, ch, accumulate, c_valid, chunk_mode);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_pack_weight_T(const float* w, float* out, int O, int C, int T, int flip, hipStream_t st) {
+  if (!w || !out || O <= 0 || C <= 0 || T <= 0) return LFSR_E_ARG;
+  long long total = (long long)T * npad32(C) * O;
+  unsigned grid = lfsr_blocks(total, 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(k_pack_weight_T, dim3(grid), dim3(256), 0, st, w, out, O, C, T, npad32(C), flip);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

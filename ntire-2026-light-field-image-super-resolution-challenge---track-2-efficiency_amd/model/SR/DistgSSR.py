@@ -53,6 +53,31 @@ class _Cascade(_Holder):
         self.conv = _dil_conv(ch, ch, A)
 
 
+class _DistgSSRFunction(torch.autograd.Function):
+    """Whole-model autograd node: forward and backward both run in the HIP library; the gradients of all 137
+    parameters come back as views of ONE flat fp32 bucket (``model.grad_bucket``) ready for a single all-reduce."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        rt = model._runtime(x.device)
+        ctx.model, ctx.rt = model, rt
+        ctx.save_for_backward(x)
+        return rt.forward_train(x)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        model, rt = ctx.model, ctx.rt
+        if model.grad_bucket is None or model.grad_bucket.device != x.device:
+            model.grad_bucket = torch.empty(rt.num_params(), dtype=torch.float32, device=x.device)
+        rt.backward(x, dout, model.grad_bucket)
+        grads = []
+        for name, p in model.named_parameters():
+            off, n = model._spans[name]
+            grads.append(model.grad_bucket[off:off + n].view_as(p) if p.requires_grad else None)
+        return (None, None, *grads)
+
+
 class get_model(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -65,11 +90,15 @@ class get_model(nn.Module):
                                       nn.PixelShuffle(self.factor), nn.Conv2d(channels, 1, kernel_size=1, bias=False))
         self._rt = None
         self._rt_version = None
+        self._spans = None
+        self.grad_bucket = None      # flat fp32 gradient bucket filled by the HIP backward (state_dict order)
 
     # -- HIP runtime plumbing ------------------------------------------------------------------------
     def _runtime(self, device):
         if self._rt is None:
             self._rt = capi.DistgSSRRuntime(self.angRes, self.factor)
+        if self._spans is None:
+            self._spans = {k: self._rt.param_span(k) for k, _ in self.named_parameters()}
         ver = (device, tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if ver != self._rt_version:   # (re)pack after load_state_dict / .to() / an optimizer step
             self._rt.load_state(self.state_dict().items(), device)
@@ -79,9 +108,10 @@ class get_model(nn.Module):
     def forward(self, x, info=None):
         if not x.is_cuda:
             raise capi.LfsrError("DistgSSR: input must live on the MI355X (no CPU fallback in the HIP path)")
+        x = x.float() if x.dtype != torch.float32 else x
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("DistgSSR HIP backward is not built yet: call under torch.no_grad()")
-        return self._runtime(x.device).forward(x.float() if x.dtype != torch.float32 else x)
+            return _DistgSSRFunction.apply(self, x, *self.parameters())      # train.py:257
+        return self._runtime(x.device).forward(x)
 
 
 class get_loss(nn.Module):
