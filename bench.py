@@ -46,12 +46,67 @@ def cpu_baseline(sd, x1):
             "sample": f"{n} x 1 patch (5x5 views of 32x32, x4) through oracle/lfsr_torch_port.py (stock torch CPU ops, fp32), {el:.1f} s"}
 
 
+def bench_train(args, rank, world, dev, dist):
+    """configs[3]: one optimisation step = forward + backward (HIP) + one RCCL all-reduce of the flat 14.3 MB gradient
+    bucket + clip + AdamW, batch 8 patches per GPU (weak scaling), fp32."""
+    import importlib
+    from argparse import Namespace
+    import torch
+    from lfsr_amd import capi
+    from lfsr_amd.synth import synth_input, synth_state_dict
+    from lfsr_amd.train_step import broadcast_parameters, train_step
+    sys.path.insert(0, capi._HERE)
+    M = importlib.import_module("model.SR.DistgSSR")
+    sys.path.remove(capi._HERE)
+    Bt = 8
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"]["DistgSSR"]["full"]
+    sd = synth_state_dict([(k, tuple(s)) for k, s in meta["spec"]], seed=0)
+    net = M.get_model(Namespace(angRes_in=A, angRes_out=A, scale_factor=S))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(dev).train()
+    broadcast_parameters(net)
+    crit = M.get_loss(None)
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
+    x = torch.from_numpy(synth_input((Bt, 1, A * H, A * W), seed=1 + rank)).to(dev)
+    y = torch.from_numpy(synth_input((Bt, 1, A * H * S, A * W * S), seed=100 + rank)).to(dev)
+    for _ in range(args.warmup):
+        train_step(net, crit, opt, x, y)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = train_step(net, crit, opt, x, y)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "5x5 x4-SR LF patches/sec (32^2->128^2), DistgSSR training step (fwd+bwd+allreduce+AdamW)",
+            "value": world * Bt * args.steps / el, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "loss": float(loss),
+            "config": {"workload": "configs[3]: DistgSSR 5x5 x4 training, batch 8 per GPU, data-parallel, one RCCL all-reduce of the flat gradient bucket",
+                       "batch_per_gpu": Bt, "parallelism": f"dp{world}"},
+            "model_tflops": 3 * FLOP_PER_PATCH * world * Bt * args.steps / el / 1e12}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["infer", "train"], default="infer",
+                    help="infer = configs[1] (headline, default); train = configs[3]: DistgSSR x4 fp32 train step, batch 8 per GPU, RCCL bucket all-reduce")
     args = ap.parse_args()
 
     import numpy as np
@@ -71,6 +126,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload == "train":
+        return bench_train(args, rank, world, dev, dist)
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"]["DistgSSR"]["full"]
     sd = synth_state_dict([(k, tuple(s)) for k, s in meta["spec"]], seed=0)
     rt = capi.DistgSSRRuntime(A, S)

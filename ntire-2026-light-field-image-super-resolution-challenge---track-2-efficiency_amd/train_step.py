@@ -1,0 +1,45 @@
+"""One data-parallel optimisation step (the hot loop of the reference's ``train()`` train.py:243-268, fp32) with the
+one exchange the path has: a single all-reduce of the flat gradient bucket the HIP backward fills (RCCL over xGMI on
+GPUs -- backend "nccl" on ROCm; gloo in the CPU tests).  The reference has no gradient exchange at all (single
+process); everything else follows it: L1 loss, ``clip_grad_norm_(1.0)`` (train.py:266), AdamW step.
+"""
+import torch
+import torch.distributed as dist
+
+
+def allreduce_bucket(bucket, group=None):
+    """Average a flat gradient bucket over the data-parallel group in ONE collective."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return bucket
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+        bucket.div_(world)
+    return bucket
+
+
+def bind_grads_to_bucket(net):
+    """Make every parameter's .grad a view of net.grad_bucket (state_dict order) so the collective and the optimizer
+    see the same memory."""
+    for name, p in net.named_parameters():
+        off, n = net._spans[name]
+        p.grad = net.grad_bucket[off:off + n].view_as(p)
+
+
+def train_step(net, criterion, optimizer, x, label, group=None, max_norm=1.0, data_info=None):
+    optimizer.zero_grad(set_to_none=True)
+    out = net(x, data_info)                     # train.py:257
+    loss = criterion(out, label, data_info)     # train.py:258
+    loss.backward()                             # train.py:264 -> HIP backward fills net.grad_bucket
+    allreduce_bucket(net.grad_bucket, group)
+    bind_grads_to_bucket(net)
+    torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=max_norm)   # train.py:266
+    optimizer.step()
+    return loss.detach(), out.detach()
+
+
+def broadcast_parameters(net, group=None, src=0):
+    """Identical replicas at start: rank ``src``'s weights to everyone."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        for p in net.parameters():
+            dist.broadcast(p.data, src=src, group=group)

@@ -115,3 +115,40 @@ def test_train_step_matches_inference_forward():
     with torch.no_grad():
         y2 = net(torch.from_numpy(x).cuda(), None)
     assert not torch.allclose(y2, y_inf, atol=1e-6)
+
+
+def test_full_train_step_vs_cpu_reference():
+    """train.py:243-268 in fp32: L1 -> backward -> clip_grad_norm_(1.0) -> AdamW(lr 2e-4, wd 1e-4); parameters after
+    two steps equal those of the same loop over the torch-CPU form of the oracle."""
+    from lfsr_amd.train_step import train_step
+    from oracle import lfsr_torch_port as T
+    A, h, w, s, B = 3, 6, 8, 2, 2
+    case, sd, x, _ = model_case("DistgSSR", "a3h6w8s2")
+    label = synth_input((B, 1, A * h * s, A * w * s), seed=2)
+    M = load_plugin()
+    net = build(M, A, s, sd)
+    crit = M.get_loss(None)
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
+    ref = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in sd.items()}
+    ropt = torch.optim.AdamW(list(ref.values()), lr=2e-4, weight_decay=1e-4)
+    losses, rlosses = [], []
+    for step in range(2):
+        loss, _ = train_step(net, crit, opt, torch.from_numpy(x).cuda(), torch.from_numpy(label).cuda())
+        losses.append(loss.item())
+        ropt.zero_grad()
+        with torch.enable_grad():
+            rl = torch.nn.functional.l1_loss(T.distgssr_forward.__wrapped__(torch.from_numpy(x), ref, A, s), torch.from_numpy(label))
+        rl.backward()
+        torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
+        ropt.step()
+        rlosses.append(rl.item())
+    assert np.allclose(losses, rlosses, atol=1e-6)
+    # AdamW's first updates are ~ lr * sign(g): an element whose gradient is at round-off level may move by +-lr in
+    # either run, so compare robustly: (almost) all elements to 2e-6, none further than the two steps can take it
+    bad = tot = 0
+    for k, p in net.named_parameters():
+        d = (p.detach().cpu() - ref[k].detach()).abs()
+        assert float(d.max()) <= 2 * 2 * 2e-4 + 1e-6, k
+        bad += int((d > 2e-6).sum())
+        tot += d.numel()
+    assert bad / tot < 1e-3, (bad, tot)
