@@ -174,6 +174,46 @@ int lfsr_distgssr_profile(lfsr_distgssr* ctx, int enable);   /* enable/disable; 
 /* waits for the recorded events, returns summed milliseconds and launch counts per class, then resets */
 int lfsr_distgssr_profile_read(lfsr_distgssr* ctx, double* ms, long long* launches);
 
+/* ------------------------------------------------------------------------------------------------
+ * e1-e7 / l1-l5: transformer operator classes (EPIT.py:74-128, LFT.py:133-246) on VCL rows (tokens == pixels).
+ * ---------------------------------------------------------------------------------------------- */
+/* nn.LayerNorm(C) over M rows of (x [+ pe[row % pe_rows]]); C in {64,128} (EPIT.py:78,83; LFT.py:142,150,211,215) */
+int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* pe, int pe_stride, long long pe_rows,
+                       const float* gamma, const float* beta, float* y, int y_stride, int y_choff, long long M, int C,
+                       float eps, void* stream);
+/* nn.Linear (no transposes needed: weight (N,K) packed by lfsr_pack_conv_weight(O=N,C=K,taps=1)); K in {64,128,256};
+ * y = act(x W^T + bias) + res;  slope 1 = identity, 0 = ReLU, else LeakyReLU. */
+int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const float* w_packed, const float* bias,
+                    const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
+                    long long M, int N, float slope, void* stream);
+/* nn.MultiheadAttention core with the reference's additive window mask evaluated as a predicate (EPIT.py:93-122,
+ * LFT.py:161-199,238-241): o = softmax(q k^T / sqrt(hd) + mask) v per head; hd in {8,16}.
+ * Sequences (s0,s1,s2) start at pixel s0*bs0+s1*bs1+s2*bs2; token (t1,t2) sits at + t1*st1 + t2*st2; token (t1,t2)
+ * attends keys [t1-l1, t1+r1) x [t2-l2, min(t2+r2, clip2 or n2)) clipped to the grid. */
+int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff,
+                         const float* v, int v_stride, int v_choff, float* o, int o_stride, int o_choff, int nheads, int hd,
+                         int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
+                         int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, void* stream);
+/* up-sampling tail shared by EPIT (EPIT.py:44-49) and LFT (LFT.py:52-57):
+ * 1x1 64->64 s^2 (no bias) + PixelShuffle(s) into the channel-last HR mosaic (B, A*h*s, A*w*s, 64) [w packed perm 1, ch 64];
+ * then LeakyReLU(slope) -> 3x3 conv 64->1 (zero pad 1 over the whole mosaic) + per-view bicubic skip of x_lr. */
+int lfsr_upsample_ps_fwd(const float* f, int f_stride, int f_choff, const float* w_packed, float* hr, int B, int A, int h, int w,
+                         int s, void* stream);
+int lfsr_hr_tail_fwd(const float* hr, const float* w3, const float* x_lr, float* out, int B, int A, int h, int w, int s,
+                     float slope, void* stream);
+
+/* Whole-model driver: EPIT forward (get_model.forward, EPIT.py:51-71).  Same life cycle as lfsr_distgssr_*. */
+typedef struct lfsr_epit lfsr_epit;
+int lfsr_epit_create(lfsr_epit** ctx, int A, int scale, int n_block, int channels);
+void lfsr_epit_destroy(lfsr_epit* ctx);
+size_t lfsr_epit_packed_bytes(const lfsr_epit* ctx);
+int lfsr_epit_set_packed(lfsr_epit* ctx, void* packed, size_t bytes);
+int lfsr_epit_load_param(lfsr_epit* ctx, const char* key, const float* data, size_t numel, void* stream);
+int lfsr_epit_finalize(lfsr_epit* ctx, void* stream);
+size_t lfsr_epit_workspace_bytes(const lfsr_epit* ctx, int B, int h, int w);
+int lfsr_epit_forward(lfsr_epit* ctx, const float* x, float* out, int B, int h, int w, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

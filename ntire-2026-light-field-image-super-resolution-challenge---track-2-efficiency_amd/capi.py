@@ -53,6 +53,20 @@ SIGNATURES = {
     "lfsr_distgssr_train_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "lfsr_distgssr_forward_train": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "lfsr_distgssr_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_sz, c_p]),
+    "lfsr_layernorm_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, C.c_longlong, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_i, c_f, c_p]),
+    "lfsr_linear_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, C.c_longlong, c_i, c_f, c_p]),
+    "lfsr_window_attn_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+                                   C.c_longlong, C.c_longlong, C.c_longlong, c_i, c_i, C.c_longlong, C.c_longlong, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_upsample_ps_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_hr_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_epit_create": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i]),
+    "lfsr_epit_destroy": (None, [c_p]),
+    "lfsr_epit_packed_bytes": (c_sz, [c_p]),
+    "lfsr_epit_set_packed": (c_i, [c_p, c_p, c_sz]),
+    "lfsr_epit_load_param": (c_i, [c_p, C.c_char_p, c_p, c_sz, c_p]),
+    "lfsr_epit_finalize": (c_i, [c_p, c_p]),
+    "lfsr_epit_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
+    "lfsr_epit_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
     "lfsr_distgssr_profile_read": (c_i, [c_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
@@ -422,3 +436,57 @@ def upsample_head(f, w0, b0, w2, x_lr, A, s):
     check(lib.lfsr_upsample_head_fwd(dev_ptr(f), f.shape[1], 0, dev_ptr(wf), dev_ptr(bf), dev_ptr(x_lr), dev_ptr(out), B, A, h, w, s, stream_ptr()),
           "upsample_head_fwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# generic whole-model runtime (EPIT, LFT, LF_InterNet drivers share one C-ABI life cycle)
+# ---------------------------------------------------------------------------------------------------
+
+class ModelRuntime:
+    """ctx = lfsr_<name>_create(...); packed weights + workspace are torch allocations owned here."""
+
+    def __init__(self, name, A, scale, *create_args):
+        self.lib = load()
+        self.name, self.A, self.scale = name, A, scale
+        self._f = lambda fn: getattr(self.lib, f"lfsr_{name}_{fn}")
+        ctx = c_p()
+        check(self._f("create")(C.byref(ctx), A, scale, *create_args), f"{name}_create")
+        self.ctx = ctx
+        self.packed = None
+        self.ws = {}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self._f("destroy")(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    def load_state(self, named_tensors, device):
+        nbytes = self._f("packed_bytes")(self.ctx)
+        if self.packed is None or self.packed.device != device:
+            self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(self._f("set_packed")(self.ctx, dev_ptr(self.packed), nbytes), f"{self.name}_set_packed")
+        st = stream_ptr()
+        for k, t in named_tensors:
+            t = t.detach().float().contiguous()
+            check(self._f("load_param")(self.ctx, k.encode(), dev_ptr(t, k), t.numel(), st), f"{self.name}_load_param({k})")
+        check(self._f("finalize")(self.ctx, st), f"{self.name}_finalize")
+
+    def forward(self, x):
+        B, c1, Hh, Ww = x.shape
+        if c1 != 1 or Hh % self.A or Ww % self.A:
+            raise LfsrError(f"bad input shape {tuple(x.shape)} for angRes {self.A}")
+        if x.dtype != torch.float32:
+            raise LfsrError(f"{self.name} HIP path computes in fp32; got {x.dtype}")
+        h, w = Hh // self.A, Ww // self.A
+        x = x.contiguous()
+        out = torch.empty((B, 1, Hh * self.scale, Ww * self.scale), dtype=torch.float32, device=x.device)
+        key = (B, h, w, x.device)
+        if key not in self.ws:
+            self.ws.clear()
+            self.ws[key] = torch.empty(self._f("workspace_bytes")(self.ctx, B, h, w), dtype=torch.uint8, device=x.device)
+        ws = self.ws[key]
+        check(self._f("forward")(self.ctx, dev_ptr(x), dev_ptr(out), B, h, w, dev_ptr(ws), ws.numel(), stream_ptr()), f"{self.name}_forward")
+        return out

@@ -13,7 +13,8 @@ enum { IN_SAME = 0, IN_CONV3 = 1, IN_ANG = 2, IN_EPIH = 3, IN_EPIV = 4,
        IN_CHK_V = 6,    // rows (b*A+v, y, x), tap = u : pixel (b,tap,v,y,x)      (transpose of OUT_EPIV)
        IN_LINE_H = 7,   // rows (.., y, x), tap = dxi : row m + pad - dxi if 0 <= x + pad - dxi < W
        IN_LINE_V = 8 }; // rows (.., y, x), tap = dyi : row m + (pad - dyi) W if 0 <= y + pad - dyi < H
-enum { OUT_SAME = 0, OUT_VIEWS = 1, OUT_EPIH = 2, OUT_EPIV = 3 };
+enum { OUT_SAME = 0, OUT_VIEWS = 1, OUT_EPIH = 2, OUT_EPIV = 3,
+       OUT_PS_HR = 4 };  // rows = VCL pixels, chunk = i*S+j : pixel ((u*h+y)*S+i, (v*w+x)*S+j) of the channel-last HR mosaic (PixelShuffle(S) + MacPI2SAI-free)
 
 struct GemmArgs {
   const float* X; int x_stride; int x_choff;
@@ -27,7 +28,8 @@ struct GemmArgs {
   int A, AA, H, W;                 // angular res, A*A, view height/width
   int ntaps;
   int CH;                          // channels per destination pixel for OUT_VIEWS/OUT_EPI* (N = chunks*CH)
-  float slope;                     // LeakyReLU slope; 1.0f = identity
+  float slope;                     // LeakyReLU slope; 1.0f = identity, 0.0f = ReLU
+  int S;                           // OUT_PS_HR: upscale factor
   int nblk_m;                      // number of row blocks (for the XCD remap)
 };
 
@@ -102,6 +104,11 @@ __device__ __forceinline__ long long dst_pixel(int m, int chunk, const GemmArgs&
   int q = m / HW;
   if (OUT == OUT_VIEWS) return ((long long)q * p.AA + chunk) * HW + yx;          // q = b, chunk = view
   if (OUT == OUT_EPIH) return ((long long)q * p.A + chunk) * HW + yx;            // q = b*A+u, chunk = v
+  if (OUT == OUT_PS_HR) {                                                         // q = b*AA + view
+    int y = yx / p.W, x = yx - y * p.W, b = q / p.AA, view = q - b * p.AA, u = view / p.A, v = view - u * p.A;
+    int i = chunk / p.S, j = chunk - i * p.S;
+    return ((long long)b * p.A * p.H * p.S + (long long)(u * p.H + y) * p.S + i) * ((long long)p.A * p.W * p.S) + (long long)(v * p.W + x) * p.S + j;
+  }
   int b = q / p.A, v = q - b * p.A;                                               // OUT_EPIV: q = b*A+v, chunk = u
   return (((long long)b * p.A + chunk) * p.A + v) * HW + yx;
 }

@@ -1,0 +1,265 @@
+// Token-wise and attention kernels of the transformer models (model/SR/EPIT.py:74-128, model/SR/LFT.py:133-246) on the
+// VCL layout, plus their shared up-sampling tail.  Tokens ARE VCL pixels: every linear / LayerNorm / FFN is row-wise
+// over (pixels, C) and never needs the reference's `rearrange` copies; only attention groups tokens into sequences, and
+// it does so by strided addressing (sequence base + t1*stride1 + t2*stride2).
+//
+//  * k_layernorm      nn.LayerNorm(C) over rows (optionally of x + pe), fp32, wave-shuffle reductions.
+//  * k_window_attn    softmax(q k^T / sqrt(hd) + window mask) v for `nheads` heads, one thread per (token, head), head
+//                     fastest so a wave touches whole 512-B token rows.  The -inf mask the reference rebuilds on the CPU
+//                     at every forward (EPIT.py:93-108 at :112; LFT.py:161-174 at :189) is a box predicate evaluated in
+//                     registers: only the valid keys are ever visited (55 of 160 for EPIT, 25 of 1024 for LFT).
+//  * k_hr_tail        LeakyReLU'd HR features -> 3x3 conv 64->1 over the whole HR mosaic (zero pad 1, EPIT.py:47-48 /
+//                     LFT.py:55-56) + per-view bicubic skip (EPIT.py:164-169, LFT.py:263-273; a = -0.75, clamped borders).
+#include "gemm_gather_kernel.h"
+#include "lfsr_internal.h"
+
+namespace {
+
+// ---------------- LayerNorm ----------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, int x_stride, int x_choff,
+                                                  const float* __restrict__ pe, int pe_stride, long long pe_rows,
+                                                  const float* __restrict__ g, const float* __restrict__ b,
+                                                  float* __restrict__ y, int y_stride, int y_choff, long long M, float eps) {
+  constexpr int LPR = C / 4;            // lanes per row
+  constexpr int RPB = 256 / LPR;        // rows per block
+  const int lr = threadIdx.x % LPR, rr = threadIdx.x / LPR;
+  const float4 gv = *reinterpret_cast<const float4*>(g + lr * 4);
+  const float4 bv = *reinterpret_cast<const float4*>(b + lr * 4);
+  for (long long row = (long long)blockIdx.x * RPB + rr; row < M; row += (long long)gridDim.x * RPB) {
+    float4 v = *reinterpret_cast<const float4*>(x + row * x_stride + x_choff + lr * 4);
+    if (pe) {
+      float4 q = *reinterpret_cast<const float4*>(pe + (row % pe_rows) * pe_stride + lr * 4);
+      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, LPR);
+    const float mu = s * (1.0f / C);
+    float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+    float q2 = dx * dx + dy * dy + dz * dz + dw * dw;
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, LPR);
+    const float rstd = 1.0f / sqrtf(q2 * (1.0f / C) + eps);
+    float4 o4 = make_float4(dx * rstd * gv.x + bv.x, dy * rstd * gv.y + bv.y, dz * rstd * gv.z + bv.z, dw * rstd * gv.w + bv.w);
+    *reinterpret_cast<float4*>(y + row * y_stride + y_choff + lr * 4) = o4;
+  }
+}
+
+// ---------------- windowed multi-head attention -----------------------------------------------------------------------
+struct AttnArgs {
+  const float* Q; int q_stride, q_choff;
+  const float* K; int k_stride, k_choff;
+  const float* V; int v_stride, v_choff;
+  float* O; int o_stride, o_choff;
+  int nheads;
+  int ns0, ns1, ns2; long long bs0, bs1, bs2;   // sequence (s0,s1,s2) -> base pixel
+  int n1, n2; long long st1, st2;               // token grid (t1,t2) and pixel strides
+  int l1, r1, l2, r2;                           // key window [t-l, t+r) per dim, clipped to the grid
+  int clip2;                                    // upper clip of dim 2 (LFT.py:168 clamps the column window with h, not w)
+  float scale;
+  long long total;                              // nseq * n1 * n2 * nheads
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_window_attn(AttnArgs p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.total) return;
+  const int head = (int)(idx % p.nheads);
+  long long t = idx / p.nheads;
+  const int t2 = (int)(t % p.n2); t /= p.n2;
+  const int t1 = (int)(t % p.n1); t /= p.n1;
+  const int s2 = (int)(t % p.ns2); t /= p.ns2;
+  const int s1 = (int)(t % p.ns1);
+  const int s0 = (int)(t / p.ns1);
+  const long long base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
+  const long long qpix = base + t1 * p.st1 + t2 * p.st2;
+  float q[HD], acc[HD];
+  {
+    const float4* qp = reinterpret_cast<const float4*>(p.Q + qpix * p.q_stride + p.q_choff + head * HD);
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) {
+      float4 v = qp[i];
+      q[4 * i] = v.x * p.scale; q[4 * i + 1] = v.y * p.scale; q[4 * i + 2] = v.z * p.scale; q[4 * i + 3] = v.w * p.scale;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < HD; ++i) acc[i] = 0.f;
+  float mx = -INFINITY, den = 0.f;
+  const int a0 = max(0, t1 - p.l1), a1 = min(p.n1, t1 + p.r1);
+  const int b0 = max(0, t2 - p.l2), b1 = min(min(p.n2, p.clip2), t2 + p.r2);
+  for (int k1 = a0; k1 < a1; ++k1) {
+    for (int k2 = b0; k2 < b1; ++k2) {
+      const long long kpix = base + k1 * p.st1 + k2 * p.st2;
+      const float4* kp = reinterpret_cast<const float4*>(p.K + kpix * p.k_stride + p.k_choff + head * HD);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < HD / 4; ++i) {
+        float4 kv = kp[i];
+        s = fmaf(q[4 * i], kv.x, s); s = fmaf(q[4 * i + 1], kv.y, s); s = fmaf(q[4 * i + 2], kv.z, s); s = fmaf(q[4 * i + 3], kv.w, s);
+      }
+      const float mn = fmaxf(mx, s);
+      const float corr = expf(mx - mn);      // exp(-inf) = 0 on the first key
+      const float pw = expf(s - mn);
+      den = den * corr + pw;
+      const float4* vp = reinterpret_cast<const float4*>(p.V + kpix * p.v_stride + p.v_choff + head * HD);
+#pragma unroll
+      for (int i = 0; i < HD / 4; ++i) {
+        float4 vv = vp[i];
+        acc[4 * i] = fmaf(pw, vv.x, acc[4 * i] * corr);
+        acc[4 * i + 1] = fmaf(pw, vv.y, acc[4 * i + 1] * corr);
+        acc[4 * i + 2] = fmaf(pw, vv.z, acc[4 * i + 2] * corr);
+        acc[4 * i + 3] = fmaf(pw, vv.w, acc[4 * i + 3] * corr);
+      }
+      mx = mn;
+    }
+  }
+  const float inv = 1.0f / den;      // an empty window gives NaN exactly like softmax over an all -inf row
+  float4* op = reinterpret_cast<float4*>(p.O + qpix * p.o_stride + p.o_choff + head * HD);
+#pragma unroll
+  for (int i = 0; i < HD / 4; ++i) op[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
+}
+
+// ---------------- HR tail: conv 3x3 64->1 over the HR mosaic + bicubic skip ------------------------------------------------
+__device__ __forceinline__ void cubic_coeffs(float t, float c[4]) {
+  const float a = -0.75f;
+  float x1 = t + 1.f, x2 = t, x3 = 1.f - t, x4 = 2.f - t;
+  c[0] = ((a * x1 - 5.f * a) * x1 + 8.f * a) * x1 - 4.f * a;
+  c[1] = ((a + 2.f) * x2 - (a + 3.f)) * x2 * x2 + 1.f;
+  c[2] = ((a + 2.f) * x3 - (a + 3.f)) * x3 * x3 + 1.f;
+  c[3] = ((a * x4 - 5.f * a) * x4 + 8.f * a) * x4 - 4.f * a;
+}
+
+__global__ __launch_bounds__(256) void k_hr_tail(const float* __restrict__ f, const float* __restrict__ w, const float* __restrict__ xlr, float* __restrict__ out,
+                                                int B, int A, int h, int wd, int S, float slope) {
+  __shared__ float sw[9 * 64];   // [tap][c]
+  for (int i = threadIdx.x; i < 9 * 64; i += 256) { int c = i / 9, t = i - c * 9; sw[t * 64 + c] = w[i]; }   // w (1,64,3,3)
+  __syncthreads();
+  const int Hs = A * h * S, Ws = A * wd * S, Hm = A * h, Wm = A * wd;
+  const long long total = (long long)B * Hs * Ws;
+  const float rs = 1.0f / (float)S;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+    const int X = (int)(g % Ws);
+    long long t = g / Ws;
+    const int Y = (int)(t % Hs);
+    const int b = (int)(t / Hs);
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = Y + ky - 1;
+      if (yy < 0 || yy >= Hs) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = X + kx - 1;
+        if (xx < 0 || xx >= Ws) continue;
+        const float4* fp = reinterpret_cast<const float4*>(f + (((long long)b * Hs + yy) * Ws + xx) * 64);
+        const float* wr = sw + (ky * 3 + kx) * 64;
+#pragma unroll 4
+        for (int c4 = 0; c4 < 16; ++c4) {
+          float4 v = fp[c4];
+          v.x = v.x >= 0.f ? v.x : v.x * slope; v.y = v.y >= 0.f ? v.y : v.y * slope;
+          v.z = v.z >= 0.f ? v.z : v.z * slope; v.w = v.w >= 0.f ? v.w : v.w * slope;
+          acc = fmaf(v.x, wr[4 * c4], acc); acc = fmaf(v.y, wr[4 * c4 + 1], acc); acc = fmaf(v.z, wr[4 * c4 + 2], acc); acc = fmaf(v.w, wr[4 * c4 + 3], acc);
+        }
+      }
+    }
+    // per-view bicubic (align_corners=False)
+    const int u = Y / (h * S), yl = Y - u * h * S, v = X / (wd * S), xl = X - v * wd * S;
+    const float sy = ((float)yl + 0.5f) * rs - 0.5f, sx = ((float)xl + 0.5f) * rs - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sx);
+    float cy[4], cx[4];
+    cubic_coeffs(sy - fy, cy);
+    cubic_coeffs(sx - fx, cx);
+    const float* img = xlr + (long long)b * Hm * Wm + (long long)(u * h) * Wm + v * wd;
+    float up = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int iy = min(max((int)fy - 1 + i, 0), h - 1);
+      float rowv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int ix = min(max((int)fx - 1 + j, 0), wd - 1);
+        rowv = fmaf(cx[j], img[(long long)iy * Wm + ix], rowv);
+      }
+      up = fmaf(cy[i], rowv, up);
+    }
+    out[g] = acc + up;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* pe, int pe_stride, long long pe_rows, const float* gamma, const float* beta,
+                       float* y, int y_stride, int y_choff, long long M, int C, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || M <= 0 || (C != 64 && C != 128)) return LFSR_E_ARG;
+  if ((x_stride | x_choff | y_stride | y_choff) & 3 || (pe && ((pe_stride & 3) || pe_rows <= 0))) return LFSR_E_ARG;
+  const int rpb = 256 / (C / 4);
+  unsigned grid = lfsr_blocks(M, rpb);
+  if (grid > 256u * 32) grid = 256u * 32;
+  if (C == 64) hipLaunchKernelGGL((k_layernorm<64>), dim3(grid), dim3(256), 0, lfsr_stream(stream), x, x_stride, x_choff, pe, pe_stride, pe_rows, gamma, beta, y, y_stride, y_choff, M, eps);
+  else hipLaunchKernelGGL((k_layernorm<128>), dim3(grid), dim3(256), 0, lfsr_stream(stream), x, x_stride, x_choff, pe, pe_stride, pe_rows, gamma, beta, y, y_stride, y_choff, M, eps);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,
+                         float* o, int o_stride, int o_choff, int nheads, int hd,
+                         int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
+                         int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, void* stream) {
+  if (!q || !k || !v || !o || nheads <= 0 || (hd != 8 && hd != 16) || ns0 <= 0 || ns1 <= 0 || ns2 <= 0 || n1 <= 0 || n2 <= 0) return LFSR_E_ARG;
+  if ((q_stride | q_choff | k_stride | k_choff | v_stride | v_choff | o_stride | o_choff) & 3) return LFSR_E_ARG;
+  AttnArgs p{};
+  p.Q = q; p.q_stride = q_stride; p.q_choff = q_choff; p.K = k; p.k_stride = k_stride; p.k_choff = k_choff;
+  p.V = v; p.v_stride = v_stride; p.v_choff = v_choff; p.O = o; p.o_stride = o_stride; p.o_choff = o_choff;
+  p.nheads = nheads; p.ns0 = ns0; p.ns1 = ns1; p.ns2 = ns2; p.bs0 = bs0; p.bs1 = bs1; p.bs2 = bs2;
+  p.n1 = n1; p.n2 = n2; p.st1 = st1; p.st2 = st2; p.l1 = l1; p.r1 = r1; p.l2 = l2; p.r2 = r2; p.clip2 = clip2 > 0 ? clip2 : n2;
+  p.scale = 1.0f / sqrtf((float)hd);
+  p.total = (long long)ns0 * ns1 * ns2 * n1 * n2 * nheads;
+  unsigned grid = lfsr_blocks(p.total, 256);
+  if (hd == 8) hipLaunchKernelGGL((k_window_attn<8>), dim3(grid), dim3(256), 0, lfsr_stream(stream), p);
+  else hipLaunchKernelGGL((k_window_attn<16>), dim3(grid), dim3(256), 0, lfsr_stream(stream), p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const float* w_packed, const float* bias,
+                    const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, void* stream) {
+  if (!x || !w_packed || !y || M <= 0 || M >= (1LL << 31) || N <= 0) return LFSR_E_ARG;
+  if (x_stride < x_choff + cin || y_stride < y_choff + N || (x_stride | x_choff) & 3) return LFSR_E_ARG;
+  GemmArgs p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.bias = bias;
+  p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
+  p.M = (int)M; p.N = N; p.Npad = npad32(N); p.A = 1; p.AA = 1; p.H = 1; p.W = 1; p.ntaps = 1; p.CH = N; p.slope = slope;
+  hipStream_t st = lfsr_stream(stream);
+  const bool two = (p.Npad % 64) == 0;
+  switch (cin) {
+    case 64: return two ? launch_gemm<IN_SAME, OUT_SAME, 64, 2>(p, st) : launch_gemm<IN_SAME, OUT_SAME, 64, 1>(p, st);
+    case 128: return two ? launch_gemm<IN_SAME, OUT_SAME, 128, 2>(p, st) : launch_gemm<IN_SAME, OUT_SAME, 128, 1>(p, st);
+    case 256: return two ? launch_gemm<IN_SAME, OUT_SAME, 256, 2>(p, st) : launch_gemm<IN_SAME, OUT_SAME, 256, 1>(p, st);
+    default: return LFSR_E_ARG;
+  }
+}
+
+int lfsr_upsample_ps_fwd(const float* f, int f_stride, int f_choff, const float* w_packed, float* hr, int B, int A, int h, int w, int s, void* stream) {
+  // 1x1 64 -> 64 s^2 (no bias) + PixelShuffle(s), written as the channel-last HR mosaic (B, A*h*s, A*w*s, 64); w packed with perm 1, ch 64
+  if (!f || !w_packed || !hr || B <= 0 || A <= 0 || h <= 0 || w <= 0 || s <= 0 || f_stride < f_choff + 64 || (f_stride | f_choff) & 3) return LFSR_E_ARG;
+  GemmArgs p{};
+  p.X = f; p.x_stride = f_stride; p.x_choff = f_choff; p.Wp = w_packed;
+  p.Y = hr; p.y_stride = 64; p.y_choff = 0;
+  p.M = B * A * A * h * w; p.N = 64 * s * s; p.Npad = p.N; p.A = A; p.AA = A * A; p.H = h; p.W = w; p.ntaps = 1; p.CH = 64; p.slope = 1.0f; p.S = s;
+  return launch_gemm<IN_SAME, OUT_PS_HR, 64, 2>(p, lfsr_stream(stream));
+}
+
+int lfsr_hr_tail_fwd(const float* hr, const float* w, const float* x_lr, float* out, int B, int A, int h, int wd, int s, float slope, void* stream) {
+  if (!hr || !w || !x_lr || !out || B <= 0 || A <= 0 || h <= 0 || wd <= 0 || s <= 0) return LFSR_E_ARG;
+  long long total = (long long)B * A * h * s * A * wd * s;
+  unsigned grid = lfsr_blocks(total, 256);
+  if (grid > 256u * 64) grid = 256u * 64;
+  hipLaunchKernelGGL(k_hr_tail, dim3(grid), dim3(256), 0, lfsr_stream(stream), hr, w, x_lr, out, B, A, h, wd, s, slope);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+}  // extern "C"

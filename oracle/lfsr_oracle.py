@@ -283,3 +283,95 @@ def psnr(a, b):
     """10 log10(1 / MSE), data_range 1.0 (formula of utils/utils.py:109 as skimage computes it)."""
     mse = np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)
     return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
+
+
+# ----------------------------------------------------------------------------------------------
+# EPIT (model/SR/EPIT.py)
+# ----------------------------------------------------------------------------------------------
+
+
+def conv3d_133(x, w):
+    """``nn.Conv3d(kernel=(1,3,3), padding=(0,1,1), bias=False)`` EPIT.py:24-32,136-142 / LFT.py:36-46:
+    a per-view 3x3 conv.  x (B,C,N,h,w), w (O,C,1,3,3)."""
+    B, C, N, h, wd = x.shape
+    y = conv2d(x.transpose(0, 2, 1, 3, 4).reshape(B * N, C, h, wd), w[:, :, 0], padding=(1, 1))
+    return y.reshape(B, N, -1, h, wd).transpose(0, 2, 1, 3, 4)
+
+
+def epit_gen_mask(h, w, k_h, k_w, dtype):
+    """``BasicTrans.gen_mask`` EPIT.py:93-108: additive (h*w, h*w) mask, 0 inside the window, -inf outside."""
+    khl, kwl = k_h // 2, k_w // 2
+    khr, kwr = k_h - khl, k_w - kwl
+    m = np.full((h, w, h, w), -np.inf, dtype=dtype)
+    for i in range(h):
+        for j in range(w):
+            m[i, j, max(0, i - khl):min(h, i + khr), max(0, j - kwl):min(w, j + kwr)] = 0.0
+    return m.reshape(h * w, h * w)
+
+
+def epit_basic_trans(buf, sd, pre, mask_field, nheads=8):
+    """``BasicTrans.forward`` EPIT.py:110-128.  buf (b,c,n,v,w) -> same shape."""
+    b, c, n, v, w = buf.shape
+    mask = epit_gen_mask(v, w, mask_field[0], mask_field[1], buf.dtype)
+    tok = buf.transpose(3, 4, 0, 2, 1).reshape(v * w, b * n, c)                   # (v w) (b n) c
+    tok = linear(tok, sd[pre + "linear_in.weight"])
+    tn = layer_norm(tok, sd[pre + "norm.weight"], sd[pre + "norm.bias"])
+    tok = mha(tn, tn, tok, sd[pre + "attention.in_proj_weight"], sd[pre + "attention.out_proj.weight"], nheads, mask) + tok
+    ff = layer_norm(tok, sd[pre + "feed_forward.0.weight"], sd[pre + "feed_forward.0.bias"])
+    ff = np.maximum(linear(ff, sd[pre + "feed_forward.1.weight"]), 0)
+    tok = linear(ff, sd[pre + "feed_forward.4.weight"]) + tok
+    tok = linear(tok, sd[pre + "linear_out.weight"])
+    return tok.reshape(v, w, b, n, -1).transpose(2, 4, 3, 0, 1)                   # b c n v w
+
+
+def epit_alt_filter(buf, sd, pre, A):
+    """``AltFilter.forward`` EPIT.py:144-161.  buf (b,c,A*A,h,w).  One epi_trans and one conv shared by both passes,
+    and the ORIGINAL input added after each pass."""
+    b, c, _, h, w = buf.shape
+    shortcut = buf
+    mf = [A * 2, 11]
+
+    def conv(t):
+        t = leaky_relu(conv3d_133(t, sd[pre + "conv.0.weight"]), 0.2)
+        t = leaky_relu(conv3d_133(t, sd[pre + "conv.2.weight"]), 0.2)
+        return conv3d_133(t, sd[pre + "conv.4.weight"])
+    # horizontal: 'b c (u v) h w -> b c (v w) u h'
+    t = buf.reshape(b, c, A, A, h, w).transpose(0, 1, 3, 5, 2, 4).reshape(b, c, A * w, A, h)
+    t = epit_basic_trans(t, sd, pre + "epi_trans.", mf)
+    t = t.reshape(b, c, A, w, A, h).transpose(0, 1, 4, 2, 5, 3).reshape(b, c, A * A, h, w)
+    buf = conv(t) + shortcut
+    # vertical: 'b c (u v) h w -> b c (u h) v w'
+    t = buf.reshape(b, c, A, A, h, w).transpose(0, 1, 2, 4, 3, 5).reshape(b, c, A * h, A, w)
+    t = epit_basic_trans(t, sd, pre + "epi_trans.", mf)
+    t = t.reshape(b, c, A, h, A, w).transpose(0, 1, 2, 4, 3, 5).reshape(b, c, A * A, h, w)
+    return conv(t) + shortcut
+
+
+def epit_forward(x, sd, A, s, dtype=np.float64, taps=None):
+    """``get_model.forward`` EPIT.py:51-71.  x (B,1,A*h,A*w) -> (B,1,A*h*s,A*w*s)."""
+    sd = _cast(sd, dtype)
+    x = np.asarray(x, dtype=dtype)
+    B, _, Hh, Ww = x.shape
+    h, w = Hh // A, Ww // A
+    lr = x.reshape(B, 1, A, h, A, w).transpose(0, 1, 2, 4, 3, 5)                  # b c u v h w
+    sr = interp_bicubic(lr.reshape(B * A * A, 1, h, w), s).reshape(B, 1, A, A, h * s, w * s)
+    sr = sr.transpose(0, 1, 2, 4, 3, 5).reshape(B, 1, A * h * s, A * w * s)
+    v = lr.reshape(B, 1, A * A, h, w)
+    buf = conv3d_133(v, sd["conv_init0.0.weight"])
+    t = buf
+    for i in (0, 2, 4):
+        t = leaky_relu(conv3d_133(t, sd[f"conv_init.{i}.weight"]), 0.2)
+    buf = t + buf
+    if taps is not None:
+        taps["init"] = buf
+    t = buf
+    nblk = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("altblock."))
+    for i in range(nblk):
+        t = epit_alt_filter(t, sd, f"altblock.{i}.", A)
+        if taps is not None and i == 0:
+            taps["alt0"] = t
+    buf = t + buf
+    mosaic = buf.reshape(B, -1, A, A, h, w).transpose(0, 1, 2, 4, 3, 5).reshape(B, -1, A * h, A * w)
+    up = pixel_shuffle(conv2d(mosaic, sd["upsampling.0.weight"]), s)
+    up = conv2d(leaky_relu(up, 0.2), sd["upsampling.3.weight"], padding=(1, 1))
+    return up + sr

@@ -1,0 +1,139 @@
+"""GPU: EPIT operator classes and whole forward (config 'EPIT 5x5 x4 inference') through the C ABI vs the numpy oracle
+(fp64, reference formulation) and the reference's golden outputs."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lfsr_amd import capi
+from lfsr_amd.synth import synth_input
+from oracle import lfsr_oracle as O
+from tests.helpers import model_case, psnr
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32)
+
+
+def test_layernorm():
+    lib = capi.load()
+    for C in (64, 128):
+        x = rnd((1000, C), 1, 2.0)
+        g, b = rnd((C,), 2), rnd((C,), 3)
+        y = torch.empty(1000, C, device="cuda")
+        xd, gd, bd = dev(x), dev(g), dev(b)          # keep the device tensors alive across the asynchronous call
+        capi.check(lib.lfsr_layernorm_fwd(capi.dev_ptr(xd), C, 0, None, 0, 0, capi.dev_ptr(gd), capi.dev_ptr(bd), capi.dev_ptr(y), C, 0, 1000, C, 1e-5,
+                                          capi.stream_ptr()), "ln")
+        ref = O.layer_norm(x.astype(np.float64), g.astype(np.float64), b.astype(np.float64))
+        assert np.abs(y.cpu().numpy() - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("cin,N,slope", [(64, 128, 1.0), (128, 256, 0.0), (256, 128, 1.0), (128, 64, 0.2), (128, 96, 1.0)])
+def test_linear(cin, N, slope):
+    lib = capi.load()
+    M = 777
+    x, w, r = rnd((M, cin), 4), rnd((N, cin), 5, 0.1), rnd((M, N), 6)
+    y = torch.empty(M, N, device="cuda")
+    xd, rd, wp = dev(x), dev(r), capi.pack_conv_weight(dev(w.reshape(N, cin, 1, 1)))
+    capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xd), cin, 0, cin, capi.dev_ptr(wp), None,
+                                   capi.dev_ptr(rd), N, 0, capi.dev_ptr(y), N, 0, M, N, slope, capi.stream_ptr()), "linear")
+    z = x.astype(np.float64) @ w.astype(np.float64).T
+    ref = np.where(z >= 0, z, z * slope) + r
+    assert np.abs(y.cpu().numpy() - ref).max() < ATOL
+
+
+@pytest.mark.parametrize("vertical", [0, 1])
+def test_epi_attention_vs_masked_mha(vertical):
+    """window predicate == the reference's additive -inf mask (EPIT.py:93-108) inside nn.MultiheadAttention's core"""
+    lib = capi.load()
+    B, A, h, w, E, NH = 2, 3, 6, 8, 128, 8
+    npix = B * A * A * h * w
+    q, k, v = rnd((npix, E), 7), rnd((npix, E), 8), rnd((npix, E), 9)
+    o = torch.empty(npix, E, device="cuda")
+    HW = h * w
+    if not vertical:
+        args = (B, A, w, A * A * HW, HW, 1, A, h, A * HW, w)
+    else:
+        args = (B, A, h, A * A * HW, A * HW, w, A, w, HW, 1)
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    capi.check(lib.lfsr_window_attn_fwd(capi.dev_ptr(qd), E, 0, capi.dev_ptr(kd), E, 0, capi.dev_ptr(vd), E, 0, capi.dev_ptr(o), E, 0, NH, E // NH,
+                                        *args, A, A, 5, 6, 0, capi.stream_ptr()), "attn")
+    # reference: tokens (L, N, E) in the rearranged order of AltFilter.forward (EPIT.py:150/156)
+    def to_seq(t):
+        t = t.astype(np.float64).reshape(B, A, A, h, w, E)                                  # b u v y x e
+        if not vertical:
+            return t.transpose(1, 3, 0, 2, 4, 5).reshape(A * h, B * A * w, E)               # (u y) (b v x)
+        return t.transpose(2, 4, 0, 1, 3, 5).reshape(A * w, B * A * h, E)                   # (v x) (b u y)
+    L = A * (w if vertical else h)
+    mask = O.epit_gen_mask(A, w if vertical else h, 2 * A, 11, np.float64)
+    Q, K, V = to_seq(q), to_seq(k), to_seq(v)
+    hd = E // NH
+    Qh = Q.reshape(L, -1, hd).transpose(1, 0, 2)
+    Kh = K.reshape(L, -1, hd).transpose(1, 0, 2)
+    Vh = V.reshape(L, -1, hd).transpose(1, 0, 2)
+    S = Qh @ Kh.transpose(0, 2, 1) / np.sqrt(hd) + mask
+    Pm = np.exp(S - S.max(-1, keepdims=True))
+    Pm /= Pm.sum(-1, keepdims=True)
+    ref_seq = (Pm @ Vh).transpose(1, 0, 2).reshape(L, -1, E)
+    got = to_seq(o.cpu().numpy())
+    assert np.abs(got - ref_seq).max() < 1e-5
+
+
+TAGS = ["a5h8s4", "a3h6w8s2"]
+
+
+def runtime(case, sd):
+    rt = capi.ModelRuntime("epit", case["A"], case["s"], 5, 64)
+    rt.load_state([(k, dev(v)) for k, v in sd.items()], torch.device("cuda", 0))
+    return rt
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_epit_small_vs_golden_and_oracle(tag):
+    case, sd, x, npz = model_case("EPIT", tag)
+    y = runtime(case, sd).forward(dev(x)).cpu().numpy()
+    gold = npz[tag + "_out"]
+    ref = O.epit_forward(x, sd, case["A"], case["s"])
+    assert np.abs(y - ref).max() < ATOL
+    assert np.abs(y - gold).max() < ATOL
+    assert psnr(y, gold) >= 80.0
+
+
+def test_epit_full_patch():
+    case, sd, x1, npz = model_case("EPIT", "full")
+    x = np.concatenate([x1, synth_input(x1.shape, seed=5)], axis=0)
+    rt = runtime(case, sd)
+    y = rt.forward(dev(x)).cpu().numpy()
+    assert y.shape == (2, 1, 640, 640)
+    assert np.abs(y[:1, :, ::8, ::8] - npz["full_sample"]).max() < ATOL          # the reference itself
+    ref = O.epit_forward(x[:1], sd, 5, 4)
+    assert np.abs(y[:1] - ref).max() < ATOL
+    label = synth_input(ref.shape, seed=2)
+    assert abs(psnr(y[:1], label) - psnr(ref, label)) <= 0.01
+    assert np.array_equal(rt.forward(dev(x[1:])).cpu().numpy(), y[1:])            # batch independence
+
+
+def test_epit_plugin_surface():
+    import importlib
+    from argparse import Namespace
+    sys.path.insert(0, capi._HERE)
+    try:
+        M = importlib.import_module("model.SR.EPIT")
+    finally:
+        sys.path.remove(capi._HERE)
+    case, sd, x, npz = model_case("EPIT", "a3h6w8s2")
+    net = M.get_model(Namespace(angRes_in=3, angRes_out=3, scale_factor=2))
+    assert [k for k in net.state_dict()] == [k for k, _ in case["spec"]]
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to("cuda:0").eval()
+    with torch.no_grad():
+        y = net(dev(x), [3, 3])
+    assert np.abs(y.cpu().numpy() - npz["a3h6w8s2_out"]).max() < ATOL

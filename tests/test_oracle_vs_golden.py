@@ -117,3 +117,13 @@ def test_torch_port_distgssr(tag):
     case, sd, x, npz = model_case("DistgSSR", tag)
     y = T.distgssr_forward(torch.from_numpy(x), {k: torch.from_numpy(v) for k, v in sd.items()}, case["A"], case["s"]).numpy()
     assert np.abs(y - npz[tag + "_out"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
+def test_epit_small(tag):
+    case, sd, x, npz = model_case("EPIT", tag)
+    y = O.epit_forward(x, sd, case["A"], case["s"])
+    g = npz[tag + "_out"]
+    assert y.shape == g.shape
+    assert np.abs(y - g).max() < 5e-5
+    assert psnr(y, g) > 95.0
