@@ -177,8 +177,8 @@ int lfsr_distgssr_profile_read(lfsr_distgssr* ctx, double* ms, long long* launch
 /* ------------------------------------------------------------------------------------------------
  * e1-e7 / l1-l5: transformer operator classes (EPIT.py:74-128, LFT.py:133-246) on VCL rows (tokens == pixels).
  * ---------------------------------------------------------------------------------------------- */
-/* nn.LayerNorm(C) over M rows of (x [+ pe[row % pe_rows]]); C in {64,128} (EPIT.py:78,83; LFT.py:142,150,211,215) */
-int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* pe, int pe_stride, long long pe_rows,
+/* nn.LayerNorm(C) over M rows of (x [+ pe[(row / pe_div) % pe_rows]]); C in {64,128} (EPIT.py:78,83; LFT.py:142,150,211,215) */
+int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* pe, int pe_stride, long long pe_rows, long long pe_div,
                        const float* gamma, const float* beta, float* y, int y_stride, int y_choff, long long M, int C,
                        float eps, void* stream);
 /* nn.Linear (no transposes needed: weight (N,K) packed by lfsr_pack_conv_weight(O=N,C=K,taps=1)); K in {64,128,256};
@@ -194,6 +194,11 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
                          const float* v, int v_stride, int v_choff, float* o, int o_stride, int o_choff, int nheads, int hd,
                          int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
                          int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, void* stream);
+/* per-view 3x3 conv 64 -> N for any N (gather-GEMM): LFT's unfold(3x3) + Linear(576 -> 128) token embedding (LFT.py:176-182) */
+int lfsr_conv3x3_n_fwd(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
+                       int n_img, int h, int w, int N, float slope, void* stream);
+/* PositionEncoding.forward (LFT.py:106-130): spa_pe (h*w, C), ang_pe (A*A, C) */
+int lfsr_lft_position_fwd(float* spa_pe, float* ang_pe, int A, int h, int w, int C, void* stream);
 /* up-sampling tail shared by EPIT (EPIT.py:44-49) and LFT (LFT.py:52-57):
  * 1x1 64->64 s^2 (no bias) + PixelShuffle(s) into the channel-last HR mosaic (B, A*h*s, A*w*s, 64) [w packed perm 1, ch 64];
  * then LeakyReLU(slope) -> 3x3 conv 64->1 (zero pad 1 over the whole mosaic) + per-view bicubic skip of x_lr. */
@@ -213,6 +218,18 @@ int lfsr_epit_finalize(lfsr_epit* ctx, void* stream);
 size_t lfsr_epit_workspace_bytes(const lfsr_epit* ctx, int B, int h, int w);
 int lfsr_epit_forward(lfsr_epit* ctx, const float* x, float* out, int B, int h, int w, void* workspace, size_t workspace_bytes,
                       void* stream);
+
+/* Whole-model driver: LFT forward (get_model.forward, LFT.py:67-98). */
+typedef struct lfsr_lft lfsr_lft;
+int lfsr_lft_create(lfsr_lft** ctx, int A, int scale, int n_layer, int channels);
+void lfsr_lft_destroy(lfsr_lft* ctx);
+size_t lfsr_lft_packed_bytes(const lfsr_lft* ctx);
+int lfsr_lft_set_packed(lfsr_lft* ctx, void* packed, size_t bytes);
+int lfsr_lft_load_param(lfsr_lft* ctx, const char* key, const float* data, size_t numel, void* stream);
+int lfsr_lft_finalize(lfsr_lft* ctx, void* stream);
+size_t lfsr_lft_workspace_bytes(const lfsr_lft* ctx, int B, int h, int w);
+int lfsr_lft_forward(lfsr_lft* ctx, const float* x, float* out, int B, int h, int w, void* workspace, size_t workspace_bytes,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,7 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
   auto trans = [&](const float* X, const std::string& e, int vertical, float* Yo) -> int {
     int r;
     if ((r = lfsr_linear_fwd(X, 64, 0, 64, P.w(e + "linear_in.weight"), nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 1.0f, stream))) return r;
-    if ((r = lfsr_layernorm_fwd(T, 128, 0, nullptr, 0, 0, P.w(e + "norm.weight"), P.w(e + "norm.bias"), TN, 128, 0, npix, 128, 1e-5f, stream))) return r;
+    if ((r = lfsr_layernorm_fwd(T, 128, 0, nullptr, 0, 0, 1, P.w(e + "norm.weight"), P.w(e + "norm.bias"), TN, 128, 0, npix, 128, 1e-5f, stream))) return r;
     const float* Win = P.w(e + "attention.in_proj_weight");
     if ((r = lfsr_linear_fwd(TN, 128, 0, 128, Win, nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 1.0f, stream))) return r;              // q | k from LN(t)
     if ((r = lfsr_linear_fwd(T, 128, 0, 128, Win + 256 * 128, nullptr, nullptr, 0, 0, V, 128, 0, npix, 128, 1.0f, stream))) return r;    // v from t
@@ -105,7 +105,7 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
                                   A, w, HW, 1, A, A, 5, 6, 0, stream);                               // sequence (b, u, y); tokens (v, x)
     if (r) return r;
     if ((r = lfsr_linear_fwd(TN, 128, 0, 128, P.w(e + "attention.out_proj.weight"), nullptr, T, 128, 0, T2, 128, 0, npix, 128, 1.0f, stream))) return r;
-    if ((r = lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, P.w(e + "feed_forward.0.weight"), P.w(e + "feed_forward.0.bias"), V, 128, 0, npix, 128, 1e-5f, stream))) return r;
+    if ((r = lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, P.w(e + "feed_forward.0.weight"), P.w(e + "feed_forward.0.bias"), V, 128, 0, npix, 128, 1e-5f, stream))) return r;
     if ((r = lfsr_linear_fwd(V, 128, 0, 128, P.w(e + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream))) return r;   // ReLU
     if ((r = lfsr_linear_fwd(QK, 256, 0, 256, P.w(e + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream))) return r;
     return lfsr_linear_fwd(T, 128, 0, 128, P.w(e + "linear_out.weight"), nullptr, nullptr, 0, 0, Yo, 64, 0, npix, 64, 1.0f, stream);

@@ -18,7 +18,7 @@ namespace {
 // ---------------- LayerNorm ----------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, int x_stride, int x_choff,
-                                                  const float* __restrict__ pe, int pe_stride, long long pe_rows,
+                                                  const float* __restrict__ pe, int pe_stride, long long pe_rows, long long pe_div,
                                                   const float* __restrict__ g, const float* __restrict__ b,
                                                   float* __restrict__ y, int y_stride, int y_choff, long long M, float eps) {
   constexpr int LPR = C / 4;            // lanes per row
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
   for (long long row = (long long)blockIdx.x * RPB + rr; row < M; row += (long long)gridDim.x * RPB) {
     float4 v = *reinterpret_cast<const float4*>(x + row * x_stride + x_choff + lr * 4);
     if (pe) {
-      float4 q = *reinterpret_cast<const float4*>(pe + (row % pe_rows) * pe_stride + lr * 4);
+      float4 q = *reinterpret_cast<const float4*>(pe + ((row / pe_div) % pe_rows) * pe_stride + lr * 4);
       v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
     float s = v.x + v.y + v.z + v.w;
@@ -187,19 +187,39 @@ __global__ __launch_bounds__(256) void k_hr_tail(const float* __restrict__ f, co
   }
 }
 
+// sin of the even columns then cos of the odd columns, concatenated; temperature 10000 (fp64 math, fp32 result)
+__device__ __forceinline__ double lft_pe(int pos, int col, int C) {
+  const int half = C / 2;
+  const int src = col < half ? 2 * col : 2 * (col - half) + 1;       // column of pos/grid that feeds this output column
+  const double g = pow(10000.0, 2.0 * (double)(src / 2) / (double)C);
+  const double a = (double)pos / g;
+  return col < half ? sin(a) : cos(a);
+}
+
+__global__ void k_lft_position(float* __restrict__ spa_pe, float* __restrict__ ang_pe, int AA, int h, int w, int C) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < h * w * C) {
+    int c = i % C, p = i / C, y = p / w, x = p - y * w;
+    spa_pe[i] = (float)((lft_pe(y, c, C) + lft_pe(x, c, C)) / 2.0);
+  } else if (i < (h * w + AA) * C) {
+    int j = i - h * w * C, c = j % C, a = j / C;
+    ang_pe[j] = (float)lft_pe(a, c, C);
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
-int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* pe, int pe_stride, long long pe_rows, const float* gamma, const float* beta,
+int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* pe, int pe_stride, long long pe_rows, long long pe_div, const float* gamma, const float* beta,
                        float* y, int y_stride, int y_choff, long long M, int C, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || M <= 0 || (C != 64 && C != 128)) return LFSR_E_ARG;
-  if ((x_stride | x_choff | y_stride | y_choff) & 3 || (pe && ((pe_stride & 3) || pe_rows <= 0))) return LFSR_E_ARG;
+  if ((x_stride | x_choff | y_stride | y_choff) & 3 || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
   const int rpb = 256 / (C / 4);
   unsigned grid = lfsr_blocks(M, rpb);
   if (grid > 256u * 32) grid = 256u * 32;
-  if (C == 64) hipLaunchKernelGGL((k_layernorm<64>), dim3(grid), dim3(256), 0, lfsr_stream(stream), x, x_stride, x_choff, pe, pe_stride, pe_rows, gamma, beta, y, y_stride, y_choff, M, eps);
-  else hipLaunchKernelGGL((k_layernorm<128>), dim3(grid), dim3(256), 0, lfsr_stream(stream), x, x_stride, x_choff, pe, pe_stride, pe_rows, gamma, beta, y, y_stride, y_choff, M, eps);
+  if (C == 64) hipLaunchKernelGGL((k_layernorm<64>), dim3(grid), dim3(256), 0, lfsr_stream(stream), x, x_stride, x_choff, pe, pe_stride, pe_rows, pe_div, gamma, beta, y, y_stride, y_choff, M, eps);
+  else hipLaunchKernelGGL((k_layernorm<128>), dim3(grid), dim3(256), 0, lfsr_stream(stream), x, x_stride, x_choff, pe, pe_stride, pe_rows, pe_div, gamma, beta, y, y_stride, y_choff, M, eps);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
@@ -240,6 +260,26 @@ int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const fl
     case 256: return two ? launch_gemm<IN_SAME, OUT_SAME, 256, 2>(p, st) : launch_gemm<IN_SAME, OUT_SAME, 256, 1>(p, st);
     default: return LFSR_E_ARG;
   }
+}
+
+int lfsr_conv3x3_n_fwd(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
+                       int n_img, int h, int w, int N, float slope, void* stream) {
+  // per-view 3x3 conv 64 -> N (any N): LFT's unfold(3x3)+Linear(576->128) token embedding (LFT.py:176-182)
+  if (!x || !w_packed || !y || n_img <= 0 || h <= 0 || w <= 0 || N <= 0 || x_stride < x_choff + 64 || y_stride < y_choff + N || (x_stride | x_choff) & 3) return LFSR_E_ARG;
+  GemmArgs p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed;
+  p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
+  p.M = n_img * h * w; p.N = N; p.Npad = npad32(N); p.A = 1; p.AA = 1; p.H = h; p.W = w; p.ntaps = 9; p.CH = N; p.slope = slope;
+  return (p.Npad % 64) == 0 ? launch_gemm<IN_CONV3, OUT_SAME, 64, 2>(p, lfsr_stream(stream)) : launch_gemm<IN_CONV3, OUT_SAME, 64, 1>(p, lfsr_stream(stream));
+}
+
+int lfsr_lft_position_fwd(float* spa_pe, float* ang_pe, int A, int h, int w, int C, void* stream) {
+  // PositionEncoding.forward (LFT.py:106-130): spa_pe (h*w, C) = (PE_h[y] + PE_w[x]) / 2 ; ang_pe (A*A, C) = PE_a[a]
+  if (!spa_pe || !ang_pe || A <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 1)) return LFSR_E_ARG;
+  int total = (h * w + A * A) * C;
+  hipLaunchKernelGGL(k_lft_position, dim3((total + 255) / 256), dim3(256), 0, lfsr_stream(stream), spa_pe, ang_pe, A * A, h, w, C);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
 }
 
 int lfsr_upsample_ps_fwd(const float* f, int f_stride, int f_choff, const float* w_packed, float* hr, int B, int A, int h, int w, int s, void* stream) {

@@ -375,3 +375,107 @@ def epit_forward(x, sd, A, s, dtype=np.float64, taps=None):
     up = pixel_shuffle(conv2d(mosaic, sd["upsampling.0.weight"]), s)
     up = conv2d(leaky_relu(up, 0.2), sd["upsampling.3.weight"], padding=(1, 1))
     return up + sr
+
+
+# ----------------------------------------------------------------------------------------------
+# LFT (model/SR/LFT.py)
+# ----------------------------------------------------------------------------------------------
+
+
+def lft_position_encoding(lengths, token_dim, dtype, temperature=10000):
+    """``PositionEncoding.forward`` LFT.py:106-130 for the listed axis lengths: returns one (len, token_dim) table per axis
+    (sin of the even columns then cos of the odd columns, concatenated -- not interleaved)."""
+    grid = np.arange(token_dim, dtype=np.float64)
+    grid = 2 * (grid // 2) / token_dim
+    grid = temperature ** grid
+    out = []
+    for n in lengths:
+        pos = np.arange(n, dtype=np.float64).reshape(-1, 1) / grid
+        out.append(np.concatenate([np.sin(pos[:, 0::2]), np.cos(pos[:, 1::2])], axis=1).astype(dtype))
+    return out
+
+
+def lft_gen_mask(h, w, k, dtype):
+    """``SpaTrans.gen_mask`` LFT.py:161-174 -- the column window is clamped with h, not w (kept)."""
+    kl = k // 2
+    kr = k - kl
+    m = np.full((h, w, h, w), -np.inf, dtype=dtype)
+    for i in range(h):
+        for j in range(w):
+            m[i, j, max(0, i - kl):min(h, i + kr), max(0, j - kl):min(h, j + kr)] = 0.0
+    return m.reshape(h * w, h * w)
+
+
+def _mha_chunked(q, k, v, in_w, out_w, nheads, mask, chunk=8):
+    """mha() over the batch axis in chunks (the spatial transformer has L=1024: bound the (N*heads, L, L) scores)."""
+    outs = [mha(q[:, i:i + chunk], k[:, i:i + chunk], v[:, i:i + chunk], in_w, out_w, nheads, mask) for i in range(0, q.shape[1], chunk)]
+    return np.concatenate(outs, axis=1)
+
+
+def lft_ang_trans(buf, sd, pre, ang_pe):
+    """``AngTrans.forward`` LFT.py:233-246.  buf (b,c,a,h,w)."""
+    b, c, a, h, w = buf.shape
+    tok = buf.transpose(2, 0, 3, 4, 1).reshape(a, b * h * w, c)                    # a (b h w) c
+    tn = layer_norm(tok + ang_pe.reshape(a, 1, c), sd[pre + "norm.weight"], sd[pre + "norm.bias"])
+    tok = _mha_chunked(tn, tn, tok, sd[pre + "attention.in_proj_weight"], sd[pre + "attention.out_proj.weight"], 8, None, chunk=4096) + tok
+    ff = layer_norm(tok, sd[pre + "feed_forward.0.weight"], sd[pre + "feed_forward.0.bias"])
+    ff = np.maximum(linear(ff, sd[pre + "feed_forward.1.weight"]), 0)
+    tok = linear(ff, sd[pre + "feed_forward.4.weight"]) + tok
+    return tok.reshape(a, b, h, w, c).transpose(1, 4, 0, 2, 3)
+
+
+def lft_spa_trans(buf, sd, pre, spa_pos):
+    """``SpaTrans.forward`` LFT.py:188-203.  buf (b,c,a,h,w); spa_pos (1,c,1,h,w)."""
+    b, c, a, h, w = buf.shape
+    mask = lft_gen_mask(h, w, 5, buf.dtype)
+    wm = sd[pre + "MLP.weight"].reshape(-1, c, 3, 3)        # unfold(k3,pad1) + Linear(576->128) == 3x3 conv, LFT.py:176-182
+
+    def sai2token(t):
+        n = t.shape[0] * t.shape[2]
+        y = conv2d(t.transpose(0, 2, 1, 3, 4).reshape(n, c, h, w), wm, padding=(1, 1))    # (n, 128, h, w)
+        return y.reshape(n, -1, h * w).transpose(2, 0, 1)                                 # (h w) n 128
+    tok = sai2token(buf)
+    pe = sai2token(spa_pos)
+    tn = layer_norm(tok + pe, sd[pre + "norm.weight"], sd[pre + "norm.bias"])
+    tok = _mha_chunked(tn, tn, tok, sd[pre + "attention.in_proj_weight"], sd[pre + "attention.out_proj.weight"], 8, mask, chunk=2) + tok
+    ff = layer_norm(tok, sd[pre + "feed_forward.0.weight"], sd[pre + "feed_forward.0.bias"])
+    ff = np.maximum(linear(ff, sd[pre + "feed_forward.1.weight"]), 0)
+    tok = linear(ff, sd[pre + "feed_forward.4.weight"]) + tok
+    t = tok.reshape(h, w, b, a, -1).transpose(2, 4, 3, 0, 1)                               # b c a h w
+    wl = sd[pre + "linear.0.weight"].reshape(c, -1)                                        # Conv3d 1x1x1 128->64
+    return np.einsum("oc,bcahw->boahw", wl, t)
+
+
+def lft_forward(x, sd, A, s, dtype=np.float64, taps=None):
+    """``get_model.forward`` LFT.py:67-98.  x (B,1,A*h,A*w) -> (B,1,A*h*s,A*w*s)."""
+    sd = _cast(sd, dtype)
+    x = np.asarray(x, dtype=dtype)
+    B, _, Hh, Ww = x.shape
+    h, w = Hh // A, Ww // A
+    lr = x.reshape(B, 1, A, h, A, w).transpose(0, 1, 2, 4, 3, 5)                           # b c a1 a2 h w
+    up = interp_bicubic(lr.reshape(B * A * A, 1, h, w), s).reshape(B, 1, A, A, h * s, w * s)
+    up = up.transpose(0, 1, 2, 4, 3, 5).reshape(B, 1, A * h * s, A * w * s)                # LFT.py:263-273
+    v = lr.reshape(B, 1, A * A, h, w)
+    buf = conv3d_133(v, sd["conv_init0.0.weight"])
+    t = buf
+    for i in (0, 2, 4):
+        t = leaky_relu(conv3d_133(t, sd[f"conv_init.{i}.weight"]), 0.2)
+    buf = t + buf
+    c = buf.shape[1]
+    ph, pw, pa = lft_position_encoding([h, w, A * A], c, dtype)
+    spa_pos = ((ph[:, None, :] + pw[None, :, :]) / 2).transpose(2, 0, 1).reshape(1, c, 1, h, w)   # dims [3,4], / len(dim)
+    ang_pe = pa                                                                                   # dims [2]
+    t = buf
+    nblk = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("altblock."))
+    for i in range(nblk):
+        t = lft_ang_trans(t, sd, f"altblock.{i}.ang_trans.", ang_pe)
+        if taps is not None and i == 0:
+            taps["ang0"] = t
+        t = lft_spa_trans(t, sd, f"altblock.{i}.spa_trans.", spa_pos)
+        if taps is not None and i == 0:
+            taps["spa0"] = t
+    buf = t + buf
+    mosaic = buf.reshape(B, c, A, A, h, w).transpose(0, 1, 2, 4, 3, 5).reshape(B, c, A * h, A * w)
+    o = pixel_shuffle(conv2d(mosaic, sd["upsampling.0.weight"]), s)
+    o = conv2d(leaky_relu(o, 0.2), sd["upsampling.3.weight"], padding=(1, 1))
+    return o + up

@@ -30,7 +30,7 @@ def test_layernorm():
         g, b = rnd((C,), 2), rnd((C,), 3)
         y = torch.empty(1000, C, device="cuda")
         xd, gd, bd = dev(x), dev(g), dev(b)          # keep the device tensors alive across the asynchronous call
-        capi.check(lib.lfsr_layernorm_fwd(capi.dev_ptr(xd), C, 0, None, 0, 0, capi.dev_ptr(gd), capi.dev_ptr(bd), capi.dev_ptr(y), C, 0, 1000, C, 1e-5,
+        capi.check(lib.lfsr_layernorm_fwd(capi.dev_ptr(xd), C, 0, None, 0, 0, 1, capi.dev_ptr(gd), capi.dev_ptr(bd), capi.dev_ptr(y), C, 0, 1000, C, 1e-5,
                                           capi.stream_ptr()), "ln")
         ref = O.layer_norm(x.astype(np.float64), g.astype(np.float64), b.astype(np.float64))
         assert np.abs(y.cpu().numpy() - ref).max() < 1e-5

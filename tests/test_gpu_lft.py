@@ -1,0 +1,106 @@
+"""GPU: LFT forward (config 'LFT 5x5 x4 full-scene inference') through the C ABI vs the numpy oracle and the reference's
+golden outputs, incl. the non-square case that exercises the reference's h-for-w clamp in gen_mask (LFT.py:168)."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lfsr_amd import capi
+from lfsr_amd.dispatch import sr_scene
+from lfsr_amd.synth import synth_input
+from oracle import lfsr_oracle as O
+from tests.helpers import model_case, psnr
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def runtime(case, sd):
+    rt = capi.ModelRuntime("lft", case["A"], case["s"], 4, 64)
+    rt.load_state([(k, dev(v)) for k, v in sd.items()], torch.device("cuda", 0))
+    return rt
+
+
+def test_position_encoding():
+    lib = capi.load()
+    A, h, w, C = 5, 6, 8, 64
+    spa = torch.empty(h * w, C, device="cuda")
+    ang = torch.empty(A * A, C, device="cuda")
+    capi.check(lib.lfsr_lft_position_fwd(capi.dev_ptr(spa), capi.dev_ptr(ang), A, h, w, C, capi.stream_ptr()), "pe")
+    ph, pw, pa = O.lft_position_encoding([h, w, A * A], C, np.float64)
+    ref = ((ph[:, None, :] + pw[None, :, :]) / 2).reshape(h * w, C)
+    assert np.abs(spa.cpu().numpy() - ref).max() < 1e-6
+    assert np.abs(ang.cpu().numpy() - pa).max() < 1e-6
+
+
+def test_spatial_window_attention_vs_masked_mha():
+    """5x5 window predicate with the h-for-w clamp == the reference's dense additive mask (LFT.py:161-174)"""
+    lib = capi.load()
+    n, h, w, E, NH = 3, 6, 8, 128, 8
+    q, k, v = [(np.random.default_rng(s).standard_normal((n * h * w, E))).astype(np.float32) for s in (1, 2, 3)]
+    qd, kd, vd = dev(q), dev(k), dev(v)
+    o = torch.empty(n * h * w, E, device="cuda")
+    capi.check(lib.lfsr_window_attn_fwd(capi.dev_ptr(qd), E, 0, capi.dev_ptr(kd), E, 0, capi.dev_ptr(vd), E, 0, capi.dev_ptr(o), E, 0, NH, E // NH,
+                                        n, 1, 1, h * w, 0, 0, h, w, w, 1, 2, 3, 2, 3, h, capi.stream_ptr()), "attn")
+    mask = O.lft_gen_mask(h, w, 5, np.float64)
+    hd = E // NH
+    def heads(t):
+        return t.astype(np.float64).reshape(n, h * w, NH, hd).transpose(0, 2, 1, 3)
+    S = heads(q) @ heads(k).transpose(0, 1, 3, 2) / np.sqrt(hd) + mask
+    Pm = np.exp(S - S.max(-1, keepdims=True))
+    Pm /= Pm.sum(-1, keepdims=True)
+    ref = (Pm @ heads(v)).transpose(0, 2, 1, 3).reshape(n * h * w, E)
+    assert np.abs(o.cpu().numpy() - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
+def test_lft_small_vs_golden_and_oracle(tag):
+    case, sd, x, npz = model_case("LFT", tag)
+    y = runtime(case, sd).forward(dev(x)).cpu().numpy()
+    gold = npz[tag + "_out"]
+    ref = O.lft_forward(x, sd, case["A"], case["s"])
+    assert np.abs(y - ref).max() < ATOL
+    assert np.abs(y - gold).max() < ATOL
+    assert psnr(y, gold) >= 80.0
+
+
+def test_lft_full_patch_and_scene():
+    case, sd, x1, npz = model_case("LFT", "full")
+    rt = runtime(case, sd)
+    y = rt.forward(dev(x1)).cpu().numpy()
+    assert np.abs(y[:, :, ::8, ::8] - npz["full_sample"]).max() < ATOL          # the reference itself, 5x5 x 32x32, x4
+    label = synth_input(y.shape, seed=2)
+    # full-scene tiling (BASELINE config 5): LFdivide -> batched LFT -> LFintegrate == per-patch loop
+    A, h0, w0 = 5, 40, 33
+    lr = torch.from_numpy(synth_input((A * h0, A * w0), seed=3)).cuda()
+    net = lambda t, info=None: rt.forward(t.contiguous())
+    out = sr_scene(net, lr, A, 4, minibatch=5).cpu().numpy()
+    sub = capi.lf_divide(lr, A, 32, 16)
+    n1, n2 = sub.shape[:2]
+    outs = [rt.forward(sub[i, j][None, None].contiguous()).cpu().numpy()[0, 0] for i in range(n1) for j in range(n2)]
+    ref = O.lf_integrate(np.stack(outs).reshape(n1, n2, 640, 640), A, 128, 64, h0 * 4, w0 * 4)
+    assert np.array_equal(out, ref)
+    assert abs(psnr(y, label) - psnr(npz["full_sample"], label[:, :, ::8, ::8])) < 1.0   # sanity only (different supports)
+
+
+def test_lft_plugin_surface():
+    import importlib
+    from argparse import Namespace
+    sys.path.insert(0, capi._HERE)
+    try:
+        M = importlib.import_module("model.SR.LFT")
+    finally:
+        sys.path.remove(capi._HERE)
+    case, sd, x, npz = model_case("LFT", "a3h6w8s2")
+    net = M.get_model(Namespace(angRes_in=3, angRes_out=3, scale_factor=2))
+    assert [k for k in net.state_dict()] == [k for k, _ in case["spec"]]
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to("cuda:0").eval()
+    with torch.no_grad():
+        y = net(dev(x), [3, 3])
+    assert np.abs(y.cpu().numpy() - npz["a3h6w8s2_out"]).max() < ATOL

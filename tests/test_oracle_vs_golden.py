@@ -127,3 +127,13 @@ def test_epit_small(tag):
     assert y.shape == g.shape
     assert np.abs(y - g).max() < 5e-5
     assert psnr(y, g) > 95.0
+
+
+@pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
+def test_lft_small(tag):
+    case, sd, x, npz = model_case("LFT", tag)
+    y = O.lft_forward(x, sd, case["A"], case["s"])
+    g = npz[tag + "_out"]
+    assert y.shape == g.shape
+    assert np.abs(y - g).max() < 5e-5
+    assert psnr(y, g) > 95.0
