@@ -35,6 +35,9 @@ struct ConvArgs {
   float slope;
 };
 
+// MASK = false: forward / plain dgrad (optional residuals R1, R2).  MASK = true: dgrad through a LeakyReLU, the operand
+// prefetched at tap 8 is the saved activation Mk instead of R1 (the two never occur together on the hot path).
+template <bool MASK>
 __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
@@ -134,9 +137,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         if (tap == 6) { hv[6] = halo_load(6, nimg, ny0, nx0); hv[7] = halo_load(7, nimg, ny0, nx0); hv[8] = halo_load(8, nimg, ny0, nx0); }
         if (tap == 7) { hv[9] = halo_load(9, nimg, ny0, nx0); hv[10] = halo_load(10, nimg, ny0, nx0); }
       }
-      if (tap == 8 && (p.R1 || p.Mk) && yy < p.H) {   // residual (or, in backward, LeakyReLU' mask) operand of this tile
-        const float* src = p.R1 ? p.R1 : p.Mk;
-        const int sst = p.R1 ? p.r1_stride : p.mk_stride, sco = p.R1 ? p.r1_choff : p.mk_choff;
+      if (tap == 8 && (MASK ? p.Mk != nullptr : p.R1 != nullptr) && yy < p.H) {   // residual (backward: LeakyReLU' mask) operand
+        const float* src = MASK ? p.Mk : p.R1;
+        const int sst = MASK ? p.mk_stride : p.r1_stride, sco = MASK ? p.mk_choff : p.r1_choff;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           int pc = (lane >> 4) + 4 * i;
@@ -206,13 +209,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         if (x0 + pc < p.W) {
           float4 v = *reinterpret_cast<const float4*>(sO + pc * LROW + ch * 4);
           long long pix = row_base + pc;
-          if (p.Mk) {
-            float4 mk = res[i];
-            if (p.R1) mk = *reinterpret_cast<const float4*>(p.Mk + pix * p.mk_stride + p.mk_choff + ch * 4);
-            v.x *= mk.x > 0.f ? 1.f : p.mk_slope; v.y *= mk.y > 0.f ? 1.f : p.mk_slope;
-            v.z *= mk.z > 0.f ? 1.f : p.mk_slope; v.w *= mk.w > 0.f ? 1.f : p.mk_slope;
+          if (MASK) {
+            if (p.Mk) {
+              v.x *= res[i].x > 0.f ? 1.f : p.mk_slope; v.y *= res[i].y > 0.f ? 1.f : p.mk_slope;
+              v.z *= res[i].z > 0.f ? 1.f : p.mk_slope; v.w *= res[i].w > 0.f ? 1.f : p.mk_slope;
+            }
+            if (p.R1) {   // not on the hot path: late load
+              float4 r = *reinterpret_cast<const float4*>(p.R1 + pix * p.r1_stride + p.r1_choff + ch * 4);
+              v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+          } else {
+            if (p.R1) { v.x += res[i].x; v.y += res[i].y; v.z += res[i].z; v.w += res[i].w; }
           }
-          if (p.R1) { v.x += res[i].x; v.y += res[i].y; v.z += res[i].z; v.w += res[i].w; }
           if (p.R2) {
             float4 r = *reinterpret_cast<const float4*>(p.R2 + pix * p.r2_stride + p.r2_choff + ch * 4);
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -239,7 +247,8 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
@@ -262,7 +271,8 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
   }
   // persistent: one 124-KB-LDS block per CU walks tiles blockIdx.x, +grid, ... (uniform cost, no queue needed)
   unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-  hipLaunchKernelGGL(k_conv3x3_halo, dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  if (mk) hipLaunchKernelGGL(k_conv3x3_halo<true>, dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL(k_conv3x3_halo<false>, dim3(grid), dim3(512), SMEM_BYTES, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
