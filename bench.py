@@ -6,7 +6,7 @@ forward of the HIP path over one batch of 32 synthetic patches already resident 
 process per GPU (torchrun env), patches are independent so ranks share no data-path collective
 ("weak" scaling: 32 patches per GPU); RCCL is used only for the barrier and the max-over-ranks clock.
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel (the per-view 3x3 64->64 gather-GEMM,
+One JSON line on rank 0.  `roofline` is for the dominant kernel (the per-view 3x3 64->64 halo-tile conv,
 77 % of DistgSSR FLOPs, MFMA-bound in fp32): algorithmic FLOPs per launch = 2 * 576 * 64 * (B*25*32*32)
 divided by that kernel's average launch duration, measured with hipEvents recorded on the launch
 stream around every launch inside the timed region.  `cpu_baseline` = the numpy oracle (fp32 mode)
@@ -182,7 +182,7 @@ def main():
                        "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "k_gemm_gather<IN_CONV3,OUT_SAME,64,2> (per-view 3x3 64->64, fp32 MFMA 32x32x2)",
+                         "kernel": "k_conv3x3_halo<false> (per-view 3x3 64->64, persistent halo-tile kernel, fp32 MFMA 32x32x2)",
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_ms, "launches_timed": conv_n},
             "model_tflops": FLOP_PER_PATCH * world * BATCH * args.steps / el / 1e12,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
