@@ -231,6 +231,18 @@ size_t lfsr_lft_workspace_bytes(const lfsr_lft* ctx, int B, int h, int w);
 int lfsr_lft_forward(lfsr_lft* ctx, const float* x, float* out, int B, int h, int w, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* Whole-model driver: LF_InterNet forward (get_model.forward, LF_InterNet.py:33-41); n_groups = n_layers = 4 upstream. */
+typedef struct lfsr_internet lfsr_internet;
+int lfsr_internet_create(lfsr_internet** ctx, int A, int scale, int n_groups, int n_layers);
+void lfsr_internet_destroy(lfsr_internet* ctx);
+size_t lfsr_internet_packed_bytes(const lfsr_internet* ctx);
+int lfsr_internet_set_packed(lfsr_internet* ctx, void* packed, size_t bytes);
+int lfsr_internet_load_param(lfsr_internet* ctx, const char* key, const float* data, size_t numel, void* stream);
+int lfsr_internet_finalize(lfsr_internet* ctx, void* stream);
+size_t lfsr_internet_workspace_bytes(const lfsr_internet* ctx, int B, int h, int w);
+int lfsr_internet_forward(lfsr_internet* ctx, const float* x, float* out, int B, int h, int w, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

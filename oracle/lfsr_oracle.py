@@ -479,3 +479,39 @@ def lft_forward(x, sd, A, s, dtype=np.float64, taps=None):
     o = pixel_shuffle(conv2d(mosaic, sd["upsampling.0.weight"]), s)
     o = conv2d(leaky_relu(o, 0.2), sd["upsampling.3.weight"], padding=(1, 1))
     return o + up
+
+
+# ----------------------------------------------------------------------------------------------
+# LF_InterNet (model/SR/LF_InterNet.py)
+# ----------------------------------------------------------------------------------------------
+
+
+def internet_forward(x, sd, A, s, dtype=np.float64, n_groups=4, n_layers=4):
+    """``get_model.forward`` LF_InterNet.py:33-41 (``make_chains`` :44-67, ``BottleNeck`` :107-124, ``ReconBlock`` :127-141).
+    x (B,1,A*h,A*w) -> (B,1,A*h*s,A*w*s).  No global skip."""
+    sd = _cast(sd, dtype)
+    x = np.asarray(x, dtype=dtype)
+    d = (A, A)
+    relu = lambda t: np.maximum(t, 0)
+    m = sai2macpi(x, A)
+    xa = conv2d(m, sd["AngFE.0.weight"], stride=d)
+    xs = conv2d(m, sd["SpaFE.0.weight"], dilation=d, padding=d)
+    ba, bs = xa, xs
+    outs_a, outs_s = [], []
+    for g in range(n_groups):
+        for l in range(n_layers):
+            p = f"CascadeInterBlock.body.{g}.chained_layers.{l}."
+            ang2 = relu(conv2d(bs, sd[p + "Spa2Ang.weight"], stride=d))
+            spa2 = pixel_shuffle(conv2d(ba, sd[p + "Ang2Spa.0.weight"]), A)
+            oa = relu(conv2d(np.concatenate((ba, ang2), 1), sd[p + "AngConvSq.weight"])) + ba
+            os_ = relu(conv2d(np.concatenate((bs, spa2), 1), sd[p + "SpaConvSq.weight"], dilation=d, padding=d)) + bs
+            ba, bs = oa, os_
+        outs_a.append(ba)
+        outs_s.append(bs)
+    ca, cs = np.concatenate(outs_a, 1), np.concatenate(outs_s, 1)
+    a = relu(conv2d(ca, sd["BottleNeck.AngBottle.weight"]))
+    cs = np.concatenate((cs, pixel_shuffle(conv2d(a, sd["BottleNeck.Ang2Spa.0.weight"]), A)), 1)
+    out = relu(conv2d(cs, sd["BottleNeck.SpaBottle.weight"], dilation=d, padding=d)) + xs
+    pre = conv2d(out, sd["ReconBlock.PreConv.weight"], dilation=d, padding=d)
+    hr = pixel_shuffle(macpi2sai(pre, A), s)
+    return conv2d(hr, sd["ReconBlock.FinalConv.weight"])

@@ -137,3 +137,12 @@ def test_lft_small(tag):
     assert y.shape == g.shape
     assert np.abs(y - g).max() < 5e-5
     assert psnr(y, g) > 95.0
+
+
+@pytest.mark.parametrize("tag", ["a5h8s2", "a3h6w8s4"])
+def test_internet_small(tag):
+    case, sd, x, npz = model_case("LF_InterNet", tag)
+    y = O.internet_forward(x, sd, case["A"], case["s"])
+    g = npz[tag + "_out"]
+    assert y.shape == g.shape
+    assert np.abs(y - g).max() < 5e-5 * max(1.0, np.abs(g).max())
