@@ -37,6 +37,81 @@ __global__ __launch_bounds__(256) void k_sai_macpi(const T* __restrict__ in, T* 
   }
 }
 
+
+// ---- a1 / a2, vectorised: 16-B global accesses on both sides, permutation through LDS ---------------------------------
+// One block = G consecutive y of one (b,c) plane = A*G input rows <-> A*G output rows (row length A*w floats, A*w % 4 == 0).
+// LDS holds the SAI-side image [u][g][A*w]; the MacPI side element (g, u, x*A+v) is LDS[u][g][v*w+x].
+template <int TO_MACPI>
+__global__ __launch_bounds__(256) void k_sai_macpi_lds(const float* __restrict__ in, float* __restrict__ out, int A, int h, int w, int G) {
+  extern __shared__ float sm[];
+  const int Wd = A * w, Hd = A * h, W4 = Wd / 4;
+  const int ygroups = (h + G - 1) / G;
+  const long long plane = blockIdx.x / ygroups;
+  const int y0 = (blockIdx.x % ygroups) * G;
+  const int g_n = min(G, h - y0);
+  const float* pin = in + plane * Hd * Wd;
+  float* pout = out + plane * Hd * Wd;
+  const int nvec = A * g_n * W4;    // float4 per side
+  if (TO_MACPI) {
+    for (int i = threadIdx.x; i < nvec; i += 256) {           // SAI rows (u*h + y0+g) -> LDS [u][g][:]
+      int c4 = i % W4, r = i / W4, g = r % g_n, u = r / g_n;
+      *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = *reinterpret_cast<const float4*>(pin + (long long)(u * h + y0 + g) * Wd + c4 * 4);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvec; i += 256) {           // MacPI rows ((y0+g)*A + u), 4 consecutive columns
+      int c4 = i % W4, r = i / W4, u = r % A, g = r / A;
+      const float* row = sm + (u * G + g) * Wd;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { int col = c4 * 4 + e, x = col / A, v = col - x * A; o[e] = row[v * w + x]; }
+      *reinterpret_cast<float4*>(pout + (long long)((y0 + g) * A + u) * Wd + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  } else {
+    for (int i = threadIdx.x; i < nvec; i += 256) {           // MacPI rows -> LDS [u][g][x*A+v]
+      int c4 = i % W4, r = i / W4, u = r % A, g = r / A;
+      *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = *reinterpret_cast<const float4*>(pin + (long long)((y0 + g) * A + u) * Wd + c4 * 4);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvec; i += 256) {           // SAI rows (u*h + y0+g)
+      int c4 = i % W4, r = i / W4, g = r % g_n, u = r / g_n;
+      const float* row = sm + (u * G + g) * Wd;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { int col = c4 * 4 + e, v = col / w, x = col - v * w; o[e] = row[x * A + v]; }
+      *reinterpret_cast<float4*>(pout + (long long)(u * h + y0 + g) * Wd + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// ---- a3, vectorised (W % 4 == 0, 4-byte elements): one thread = 4 consecutive x of one (b,c,y,i): r float4 loads (one per j
+// plane), an r x 4 register transpose, r float4 stores of 4r contiguous outputs
+template <int R>
+__global__ __launch_bounds__(256) void k_pixel_shuffle2d_vec(const float* __restrict__ in, float* __restrict__ out, int BC, int H, int W) {
+  const int W4 = W / 4;
+  const long long total = (long long)BC * H * R * W4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    int x4 = (int)(idx % W4);
+    long long t = idx / W4;
+    int i = (int)(t % R); t /= R;
+    int y = (int)(t % H);
+    long long bc = t / H;
+    float v[R][4];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float4 q = *reinterpret_cast<const float4*>(in + ((bc * R * R + i * R + j) * H + y) * W + x4 * 4);
+      v[j][0] = q.x; v[j][1] = q.y; v[j][2] = q.z; v[j][3] = q.w;
+    }
+    float* o = out + (bc * H * R + (long long)y * R + i) * ((long long)W * R) + (long long)x4 * 4 * R;
+    float flat[4 * R];
+#pragma unroll
+    for (int xx = 0; xx < 4; ++xx)
+#pragma unroll
+      for (int j = 0; j < R; ++j) flat[xx * R + j] = v[j][xx];
+#pragma unroll
+    for (int q = 0; q < R; ++q) *reinterpret_cast<float4*>(o + q * 4) = make_float4(flat[4 * q], flat[4 * q + 1], flat[4 * q + 2], flat[4 * q + 3]);
+  }
+}
+
 // ---- a3: out[b,c,y*r+i,x*r+j] = in[b,c*r*r+i*r+j,y,x] ------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_pixel_shuffle2d(const T* __restrict__ in, T* __restrict__ out, int BC, int r, int H, int W) {
@@ -194,6 +269,16 @@ int lfsr_sai2macpi(const void* in, void* out, int B, int C, int A, int h, int w,
   long long total = (long long)B * C * A * h * A * w;
   if (total == 0) return LFSR_OK;  // empty tensors carry NULL pointers
   if (!in || !out) return LFSR_E_ARG;
+  if (elem_bytes == 4 && (A * w) % 4 == 0 && !(((uintptr_t)in | (uintptr_t)out) & 15)) {
+    int G = 8;                                             // y rows per block: A*G*A*w*4 bytes of LDS
+    while (G > 1 && (size_t)A * G * A * w * 4 > 48 * 1024) G >>= 1;
+    if ((size_t)A * G * A * w * 4 <= 64 * 1024) {
+      long long nblk = (long long)B * C * ((h + G - 1) / G);
+      hipLaunchKernelGGL((k_sai_macpi_lds<1>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
+      LFSR_CHECK_LAUNCH();
+      return LFSR_OK;
+    }
+  }
   if (elem_bytes == 4)
     hipLaunchKernelGGL((k_sai_macpi<uint32_t, 1>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint32_t*)in, (uint32_t*)out, B * C, A, h, w);
   else
@@ -207,6 +292,16 @@ int lfsr_macpi2sai(const void* in, void* out, int B, int C, int A, int h, int w,
   long long total = (long long)B * C * A * h * A * w;
   if (total == 0) return LFSR_OK;  // empty tensors carry NULL pointers
   if (!in || !out) return LFSR_E_ARG;
+  if (elem_bytes == 4 && (A * w) % 4 == 0 && !(((uintptr_t)in | (uintptr_t)out) & 15)) {
+    int G = 8;                                             // y rows per block: A*G*A*w*4 bytes of LDS
+    while (G > 1 && (size_t)A * G * A * w * 4 > 48 * 1024) G >>= 1;
+    if ((size_t)A * G * A * w * 4 <= 64 * 1024) {
+      long long nblk = (long long)B * C * ((h + G - 1) / G);
+      hipLaunchKernelGGL((k_sai_macpi_lds<0>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
+      LFSR_CHECK_LAUNCH();
+      return LFSR_OK;
+    }
+  }
   if (elem_bytes == 4)
     hipLaunchKernelGGL((k_sai_macpi<uint32_t, 0>), dim3(grid_for(total)), dim3(256), 0, lfsr_stream(stream), (const uint32_t*)in, (uint32_t*)out, B * C, A, h, w);
   else
@@ -220,6 +315,20 @@ int lfsr_pixel_shuffle2d(const void* in, void* out, int B, int C, int r, int H, 
   long long total = (long long)B * C * H * r * W * r;
   if (total == 0) return LFSR_OK;
   if (!in || !out) return LFSR_E_ARG;
+  if (elem_bytes == 4 && W % 4 == 0 && r >= 2 && r <= 5 && !(((uintptr_t)in | (uintptr_t)out) & 15)) {
+    long long work = (long long)B * C * H * r * (W / 4);
+    unsigned grid = grid_for(work);
+    hipStream_t st = lfsr_stream(stream);
+    const float* fi = (const float*)in; float* fo = (float*)out;
+    switch (r) {
+      case 2: hipLaunchKernelGGL((k_pixel_shuffle2d_vec<2>), dim3(grid), dim3(256), 0, st, fi, fo, B * C, H, W); break;
+      case 3: hipLaunchKernelGGL((k_pixel_shuffle2d_vec<3>), dim3(grid), dim3(256), 0, st, fi, fo, B * C, H, W); break;
+      case 4: hipLaunchKernelGGL((k_pixel_shuffle2d_vec<4>), dim3(grid), dim3(256), 0, st, fi, fo, B * C, H, W); break;
+      default: hipLaunchKernelGGL((k_pixel_shuffle2d_vec<5>), dim3(grid), dim3(256), 0, st, fi, fo, B * C, H, W); break;
+    }
+    LFSR_CHECK_LAUNCH();
+    return LFSR_OK;
+  }
   DISPATCH_ELEM(k_pixel_shuffle2d, grid_for(total), lfsr_stream(stream), B * C, r, H, W);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
