@@ -99,20 +99,31 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs p) {
 
 // sum partial slabs in split order and scatter to the PyTorch layout (O, C, T): inverse of k_pack_weight.
 // P2 (optional) is a second partial set with the same geometry (the vertical EPI pass shares its weights).
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ P, int nsplit, const float* __restrict__ P2, int nsplit2,
+__global__ __launch_bounds__(512) void k_wgrad_reduce(const float* __restrict__ P, int nsplit, const float* __restrict__ P2, int nsplit2,
                                                       float* __restrict__ dW, int O, int C, int T, int Npad, int perm, int ch, int accumulate, int c_valid, int chunk_mode) {
+  // block = 64 elements x 8 split groups: group y sums slabs y, y+8, ... (fixed order), then the 8 group sums are added in
+  // fixed order through LDS -> bitwise reproducible, and 8x the memory-level parallelism of one thread per element
+  __shared__ float red[8][64];
   const long long total = (long long)T * Npad * C;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+  const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+  const int gy = threadIdx.y;
+  float s = 0.f;
+  if (i < total) {
+    for (int sp = gy; sp < nsplit; sp += 8) s += P[(long long)sp * total + i];
+    for (int sp = gy; sp < nsplit2; sp += 8) s += P2[(long long)sp * total + i];
+  }
+  red[gy][threadIdx.x] = s;
+  __syncthreads();
+  if (gy != 0 || i >= total) return;
+  s = red[0][threadIdx.x];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) s += red[g][threadIdx.x];
   int c = (int)(i % C);
   long long t2 = i / C;
   int n = (int)(t2 % Npad);
   int t = (int)(t2 / Npad);
   if (c >= c_valid) return;
   if (chunk_mode ? n >= ch : n >= O) return;
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += P[(long long)sp * total + i];
-  for (int sp = 0; sp < nsplit2; ++sp) s += P2[(long long)sp * total + i];
   int nref = n;
   if (perm == 1) { int r2 = O / ch; int q = n / ch, cc = n - q * ch; nref = cc * r2 + q; }
   long long o = ((long long)nref * c_valid + c) * T + t;
@@ -191,7 +202,7 @@ int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, 
   if (!P || !dW || O <= 0 || C <= 0 || T <= 0) return LFSR_E_ARG;
   const int Npad = chunk_mode ? npad32(ch) : npad32(O);
   long long total = (long long)T * Npad * C;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(lfsr_blocks(total, 256)), dim3(256), 0, st, P, nsplit, P2, P2 ? nsplit2 : 0, dW, O, C, T, Npad, perm, ch, accumulate, c_valid, chunk_mode);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(lfsr_blocks(total, 64)), dim3(64, 8), 0, st, P, nsplit, P2, P2 ? nsplit2 : 0, dW, O, C, T, Npad, perm, ch, accumulate, c_valid, chunk_mode);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
