@@ -16,6 +16,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef LFSR_CONV_DIAG
+// diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
+#define STAMP(k) do { if (wave == 0) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int TR = 8, TC = 32, LROW = 68;
@@ -78,6 +85,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
   const float* bBase = sB + l31 * LROW + 4 * half;
   float* sO = sA + wave * 32 * LROW;   // epilogue transposition region (wave-private, inside the dead halo)
 
+#ifdef LFSR_CONV_DIAG
+  long long seg[6] = {0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+  float* dbgbuf = const_cast<float*>(p.R2);
+  p.R2 = nullptr;
+#endif
   int tile = blockIdx.x;
   int img, y0, x0;
   tile_origin(tile, img, y0, x0);
@@ -103,6 +116,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
       if (hoff[i] >= 0) *reinterpret_cast<float4*>(sA + hoff[i] * LROW + c16 * 4) = hv[i];
     // LDS-only barrier: the previous tile's output stores stay in flight (a __syncthreads would drain vmcnt)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    STAMP(4);   // halo LDS write + barrier
 
     const int next = tile + gridDim.x;
     const bool has_next = next < ntiles;
@@ -187,7 +201,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         if (j < 7 || tap < 8) { fa = na; fb0 = nb0f; fb1 = nb1f; }
       }
     }
+    STAMP(0);   // 9 taps
     __syncthreads();   // all waves are done reading the halo (and tap 8's slab) before the epilogue reuses the region
+    STAMP(1);   // seam barrier wait
 
     // ---- epilogue: accumulators -> LDS [pixel][channel] -> 16-B stores (256 B contiguous per pixel) ----
     // C/D layout: channel n = lane&31 (+32 for acc1), pixel column = (reg&3) + 8*(reg>>2) + 4*half
@@ -229,11 +245,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         }
       }
     }
+    STAMP(2);   // transposition + output stores issued
     if (!has_next) break;
     // every wave is done with its sO reads before the halo region is overwritten (LDS-only barrier, stores keep flying)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    STAMP(3);   // barrier after the epilogue
     tile = next; img = nimg; y0 = ny0; x0 = nx0;
   }
+#ifdef LFSR_CONV_DIAG
+  if (dbgbuf && tid == 0)
+    for (int k = 0; k < 6; ++k) dbgbuf[blockIdx.x * 8 + k] = (float)seg[k];
+#endif
 }
 
 }  // namespace

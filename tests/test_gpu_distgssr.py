@@ -215,3 +215,37 @@ def test_distgssr_plugin_surface():
         y2 = net(dev(x), [3, 3])
     ref_skip = O.interp_bilinear(x.astype(np.float64), 2)
     assert np.abs(y2.cpu().numpy() - ref_skip).max() < 1e-5
+
+
+# ---- geometries beyond one 32-column tile / one fused-EPI line: the generic paths ----------------------------------------
+
+@pytest.mark.parametrize("B,A,h,w", [(1, 3, 40, 48), (1, 5, 33, 36)])
+def test_ops_large_views(B, A, h, w):
+    """views wider than the 32-column conv tile (several tiles per image) and longer than a fused EPI line (gather-GEMM fallback)"""
+    x = rnd((B, 64, A * h, A * w), 31)
+    wt = rnd((64, 64, 3, 3), 32, 0.05)
+    ref = O.leaky_relu(O.conv2d(x.astype(np.float64), wt.astype(np.float64), dilation=(A, A), padding=(A, A)), 0.1)
+    y = capi.conv3x3(to_vcl(x, A), capi.pack_conv_weight(dev(wt)), B * A * A, h, w, slope=0.1)
+    assert np.abs(from_vcl(y, B, 64, A, h, w) - ref).max() < ATOL
+    w1 = rnd((32, 64, 1, A * A), 33, 0.03)
+    w2 = rnd((A * 32, 32, 1, 1), 34, 0.15)
+
+    def epi(t):
+        e = O.leaky_relu(O.conv2d(t, w1.astype(np.float64), stride=(1, A), padding=(0, A * (A - 1) // 2)), 0.1)
+        return O.pixel_shuffle1d(O.leaky_relu(O.conv2d(e, w2.astype(np.float64)), 0.1), A)
+    x64 = x.astype(np.float64)
+    out = torch.zeros((B * A * A * h * w, 144), device="cuda")
+    capi.epiconv_hv(to_vcl(x, A), capi.pack_conv_weight(dev(w1)), capi.pack_conv_weight(dev(w2)), B, A, h, w, 0.1, out, 80, 112)
+    assert np.abs(from_vcl(out, B, 32, A, h, w, choff=80) - epi(x64)).max() < ATOL
+    assert np.abs(from_vcl(out, B, 32, A, h, w, choff=112) - epi(np.ascontiguousarray(x64.transpose(0, 1, 3, 2))).transpose(0, 1, 3, 2)).max() < ATOL
+
+
+def test_distgssr_large_view_patch():
+    """whole forward on 40x36 views (not the 32x32 the kernels are tuned for) against the oracle"""
+    case, sd, _, _ = model_case("DistgSSR", "a3h6w8s2")
+    A, s, h, w = 3, 2, 40, 36
+    x = synth_input((1, 1, A * h, A * w), seed=11)
+    rt = build_runtime(case, sd)
+    y = rt.forward(dev(x)).cpu().numpy()
+    ref = O.distgssr_forward(x, sd, A, s)
+    assert np.abs(y - ref).max() < ATOL

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a persistent conv3x3 block spends its cycles (wave 0's s_memtime deltas per segment).
+Needs a library built with -DLFSR_CONV_DIAG; usage: python tools/conv_stamp.py lib.so"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lfsr_amd import capi
+capi.LIB_PATH = os.path.abspath(sys.argv[1])
+lib = capi.load()
+n_img, h, w = 800, 32, 32
+M = n_img * h * w
+x = torch.randn(M, 64, device="cuda"); wt = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+wp = capi.pack_conv_weight(wt); y = torch.empty(M, 64, device="cuda"); r = torch.randn(M, 64, device="cuda")
+dbg = torch.zeros(256 * 8 // 4, 4, device="cuda")   # 2-D so the wrapper takes a stride; stride is unused by the DIAG build
+for res in (None, r):
+    for _ in range(5):
+        capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=res, res2=dbg, out=y)   # R2 carries the debug buffer in the DIAG build
+    torch.cuda.synchronize()
+    d = dbg.reshape(256, 8).cpu().double()
+    names = ["9 taps", "seam barrier wait", "transpose+stores", "post-epilogue barrier", "halo LDS write+barrier", "-"]
+    tot = d[:, :5].sum(1).mean()
+    print(f"residual={res is not None}: mean cycles per block {tot:.0f} (tiles per block ~12.5)")
+    for k in range(5):
+        print(f"   {names[k]:26s} {d[:, k].mean():12.0f} cyc  {100 * d[:, k].mean() / tot:5.1f}%   per tile {d[:, k].mean() / 12.5:9.0f}")
