@@ -231,6 +231,14 @@ size_t lfsr_lft_workspace_bytes(const lfsr_lft* ctx, int B, int h, int w);
 int lfsr_lft_forward(lfsr_lft* ctx, const float* x, float* out, int B, int h, int w, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ---- "next" rows: the steps either side of the hot path in the training loop, on the device ----
+ * N2: cal_metrics (utils/utils.py:91-134): per-view PSNR (and SSIM, skimage semantics with gaussian_weights=True) of two
+ * (B,1,A*H,A*W) SAI mosaics, fp64 accumulation; psnr/ssim: B*A*A doubles (ssim may be NULL; SSIM needs views >= 11x11). */
+int lfsr_view_metrics(const float* label, const float* out, double* psnr, double* ssim, int B, int A, int H, int W, void* stream);
+/* N3: MaskedAngularPretraining.forward, utils/masked_pretraining.py:85-139: y = x with the views flagged in mask[A*A]
+ * (device bytes) filled with `fill` ('zero' / 'mean' strategies; the reference applies one mask to the whole batch). */
+int lfsr_mask_views(const float* x, float* y, const unsigned char* mask, float fill, int B, int C, int A, int h, int w, void* stream);
+
 /* Whole-model driver: LF_InterNet forward (get_model.forward, LF_InterNet.py:33-41); n_groups = n_layers = 4 upstream. */
 typedef struct lfsr_internet lfsr_internet;
 int lfsr_internet_create(lfsr_internet** ctx, int A, int scale, int n_groups, int n_layers);

@@ -56,6 +56,8 @@ SIGNATURES = {
     "lfsr_layernorm_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, C.c_longlong, C.c_longlong, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_i, c_f, c_p]),
     "lfsr_conv3x3_n_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_lft_position_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_view_metrics": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_mask_views": (c_i, [c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_internet_create": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i]),
     "lfsr_internet_destroy": (None, [c_p]),
     "lfsr_internet_packed_bytes": (c_sz, [c_p]),

@@ -1,0 +1,83 @@
+"""Masked angular pre-training on the device: the reference's ``MaskedAngularPretraining`` /
+``ProgressiveMasking`` (utils/masked_pretraining.py:34-226), same constructor arguments, strategies, 50 % skip, never-mask-the-
+centre rule and ``(x_masked, mask_info)`` return; the view fill runs as one kernel through the C ABI instead of a Python loop of
+slice assignments.  View selection stays on the host with Python's ``random`` exactly as upstream (so a seeded run picks the same
+views).  ``mask_value='noise'`` (host-generated randn per view upstream) is not built."""
+import random
+
+import torch
+import torch.nn as nn
+
+from lfsr_amd import capi
+
+
+class MaskedAngularPretraining(nn.Module):
+    def __init__(self, angRes=5, mask_ratio=0.3, mask_strategy='random', mask_value='zero', enable_in_eval=False):
+        super().__init__()
+        self.angRes = angRes
+        self.mask_ratio = mask_ratio
+        self.mask_strategy = mask_strategy
+        self.mask_value = mask_value
+        self.enable_in_eval = enable_in_eval
+        self.total_views = angRes * angRes
+        self.num_masked = max(1, int(self.total_views * mask_ratio))
+        self.center = (angRes // 2, angRes // 2)
+
+    def _get_mask_indices(self):
+        # masked_pretraining.py:140-170
+        A = self.angRes
+        views = [(i, j) for i in range(A) for j in range(A) if (i, j) != self.center]
+        if self.mask_strategy == 'grid':
+            return [(i, j) for i, j in views if (i + j) % 2 == 0][:self.num_masked]
+        if self.mask_strategy == 'corners':
+            corners = [(0, 0), (0, A - 1), (A - 1, 0), (A - 1, A - 1)]
+            return [c for c in corners if c in views][:self.num_masked]
+        if self.mask_strategy == 'center':
+            d = sorted(((abs(i - self.center[0]) + abs(j - self.center[1]), (i, j)) for i, j in views), key=lambda t: t[0])
+            return [v for _, v in d[:self.num_masked]]
+        return random.sample(views, min(self.num_masked, len(views)))
+
+    def forward(self, x):
+        if not self.training and not self.enable_in_eval:
+            return x, {'masked': False, 'mask_ratio': 0.0}
+        if random.random() > 0.5:
+            return x, {'masked': False, 'mask_ratio': 0.0}
+        if self.mask_value not in ('zero', 'mean'):
+            raise NotImplementedError("mask_value 'noise' is not built on the device path")
+        B, C, H, W = x.shape
+        A = self.angRes
+        idx = self._get_mask_indices()
+        if self.mask_value == 'mean' and len(idx) > 1:
+            raise NotImplementedError("mask_value 'mean' fills each view with its own mean upstream; device path supports one view")
+        flags = torch.zeros(A * A, dtype=torch.uint8)
+        for (i, j) in idx:
+            flags[i * A + j] = 1
+        flags = flags.to(x.device)
+        fill = 0.0
+        if self.mask_value == 'mean':
+            (i, j), h, w = idx[0], H // A, W // A
+            fill = float(x[:, :, i * h:(i + 1) * h, j * w:(j + 1) * w].mean())
+        xin = x.detach().float().contiguous()
+        out = torch.empty_like(xin)
+        capi.check(capi.load().lfsr_mask_views(capi.dev_ptr(xin), capi.dev_ptr(out), capi.dev_ptr(flags), fill, B, C, A, H // A, W // A,
+                                               capi.stream_ptr()), "mask_views")
+        return out, {'masked': True, 'mask_ratio': len(idx) / self.total_views, 'mask_indices': idx, 'strategy': self.mask_strategy}
+
+
+class ProgressiveMasking(nn.Module):
+    # masked_pretraining.py:173-226
+    def __init__(self, angRes=5, start_ratio=0.1, end_ratio=0.4, warmup_epochs=20):
+        super().__init__()
+        self.angRes, self.start_ratio, self.end_ratio, self.warmup_epochs = angRes, start_ratio, end_ratio, warmup_epochs
+        self.current_epoch = 0
+        self.masker = MaskedAngularPretraining(angRes=angRes, mask_ratio=start_ratio)
+
+    def set_epoch(self, epoch):
+        self.current_epoch = epoch
+        progress = min(1.0, epoch / self.warmup_epochs)
+        ratio = self.start_ratio + progress * (self.end_ratio - self.start_ratio)
+        self.masker.mask_ratio = ratio
+        self.masker.num_masked = max(1, int(self.masker.total_views * ratio))
+
+    def forward(self, x):
+        return self.masker(x)

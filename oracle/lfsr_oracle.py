@@ -515,3 +515,41 @@ def internet_forward(x, sd, A, s, dtype=np.float64, n_groups=4, n_layers=4):
     pre = conv2d(out, sd["ReconBlock.PreConv.weight"], dilation=d, padding=d)
     hr = pixel_shuffle(macpi2sai(pre, A), s)
     return conv2d(hr, sd["ReconBlock.FinalConv.weight"])
+
+
+# ----------------------------------------------------------------------------------------------
+# N2: per-view PSNR / SSIM of cal_metrics (utils/utils.py:91-134; skimage semantics restated -- skimage itself is absent)
+# ----------------------------------------------------------------------------------------------
+
+
+def _gauss11(img):
+    """scipy.ndimage.gaussian_filter(img, sigma=1.5, truncate=3.5, mode='reflect') -- what
+    skimage.metrics.structural_similarity(gaussian_weights=True) calls: separable 11-tap, edge-including mirror."""
+    k = np.exp(-0.5 * (np.arange(-5, 6) / 1.5) ** 2)
+    k /= k.sum()
+    H, W = img.shape
+    ys, xs = _sym(np.arange(-5, H + 5), H), _sym(np.arange(-5, W + 5), W)
+    p = img[:, xs]
+    h = sum(k[i] * p[:, i:i + W] for i in range(11))
+    p = h[ys, :]
+    return sum(k[i] * p[i:i + H, :] for i in range(11))
+
+
+def view_psnr_ssim(label, out, A):
+    """label/out (B,1,A*H,A*W) -> (psnr, ssim) arrays (B,A,A), float64: the per-view values cal_metrics averages."""
+    label, out = np.asarray(label, np.float64), np.asarray(out, np.float64)
+    B, _, Hh, Ww = label.shape
+    H, W = Hh // A, Ww // A
+    ps, ss = np.zeros((B, A, A)), np.zeros((B, A, A))
+    C1, C2, cov = 0.01 ** 2, 0.03 ** 2, 121.0 / 120.0
+    for b in range(B):
+        for u in range(A):
+            for v in range(A):
+                x, y = label[b, 0, u * H:(u + 1) * H, v * W:(v + 1) * W], out[b, 0, u * H:(u + 1) * H, v * W:(v + 1) * W]
+                mse = np.mean((x - y) ** 2)
+                ps[b, u, v] = 10 * np.log10(1.0 / mse) if mse > 0 else np.inf
+                ux, uy, uxx, uyy, uxy = _gauss11(x), _gauss11(y), _gauss11(x * x), _gauss11(y * y), _gauss11(x * y)
+                vx, vy, vxy = cov * (uxx - ux * ux), cov * (uyy - uy * uy), cov * (uxy - ux * uy)
+                S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+                ss[b, u, v] = S[5:-5, 5:-5].mean()
+    return ps, ss
