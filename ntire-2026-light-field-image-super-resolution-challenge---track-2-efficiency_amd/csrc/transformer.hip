@@ -10,6 +10,8 @@
 //                     registers: only the valid keys are ever visited (55 of 160 for EPIT, 25 of 1024 for LFT).
 //  * k_hr_tail        LeakyReLU'd HR features -> 3x3 conv 64->1 over the whole HR mosaic (zero pad 1, EPIT.py:47-48 /
 //                     LFT.py:55-56) + per-view bicubic skip (EPIT.py:164-169, LFT.py:263-273; a = -0.75, clamped borders).
+#include <stdlib.h>
+
 #include "gemm_gather_kernel.h"
 #include "lfsr_internal.h"
 
@@ -118,6 +120,89 @@ __global__ __launch_bounds__(256) void k_window_attn(AttnArgs p) {
   float4* op = reinterpret_cast<float4*>(p.O + qpix * p.o_stride + p.o_choff + head * HD);
 #pragma unroll
   for (int i = 0; i < HD / 4; ++i) op[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
+}
+
+
+// ---- windowed attention, LDS-tiled ------------------------------------------------------------------------------------------
+// One block = a tile of query tokens (T1 consecutive t1 rows x all n2 columns of one sequence) x HB heads.  The K and V
+// slices (HD floats each per head) of every key the tile can see -- rows [t1_lo - l1, t1_hi + r1) clipped, all columns -- are
+// staged in LDS once ([key][head][k16 | v16], token stride padded by 4 floats: ds_read_b128 conflict-free), then one thread per
+// (query token, head) walks its window reading LDS.  Against the L1-served k_window_attn this cuts the key traffic per query
+// from ~55 x 128 B of L1 reads to LDS reads, and HBM/L2 traffic to one read of K and V per tile.
+template <int HD, int HB>
+__global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, int ntile1) {
+  extern __shared__ __attribute__((aligned(16))) float skv[];
+  constexpr int TS = HB * 2 * HD + 4;                 // floats per staged key token
+  const int hb = blockIdx.y * HB;                     // first head of this block
+  int t = blockIdx.x;
+  const int tile1 = t % ntile1; t /= ntile1;
+  const int s2 = t % p.ns2; t /= p.ns2;
+  const int s1 = t % p.ns1;
+  const int s0 = t / p.ns1;
+  const long long base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
+  const int q_lo = tile1 * T1, q_hi = min(p.n1, q_lo + T1);
+  const int k_lo = max(0, q_lo - p.l1), k_hi = min(p.n1, q_hi - 1 + p.r1);
+  const int nkey = (k_hi - k_lo) * p.n2;
+  // stage K | V : one 16-B chunk per thread-iteration; chunk c of a (key, head): c < HD/4 -> K, else V
+  constexpr int CPT = 2 * HD / 4;                     // chunks per (key, head)
+  for (int i = threadIdx.x; i < nkey * HB * CPT; i += blockDim.x) {
+    int c = i % CPT, r = i / CPT, h = r % HB, key = r / HB;
+    int k1 = k_lo + key / p.n2, k2 = key % p.n2;
+    long long pix = base + k1 * p.st1 + k2 * p.st2;
+    const float* src = c < HD / 4 ? p.K + pix * p.k_stride + p.k_choff + (hb + h) * HD + c * 4
+                                  : p.V + pix * p.v_stride + p.v_choff + (hb + h) * HD + (c - HD / 4) * 4;
+    *reinterpret_cast<float4*>(skv + key * TS + h * 2 * HD + c * 4) = *reinterpret_cast<const float4*>(src);
+  }
+  __syncthreads();
+  const int nq = (q_hi - q_lo) * p.n2;
+  for (int it = threadIdx.x; it < nq * HB; it += blockDim.x) {
+    const int h = it % HB, qi = it / HB;
+    const int t1 = q_lo + qi / p.n2, t2 = qi % p.n2;
+    const long long qpix = base + t1 * p.st1 + t2 * p.st2;
+    float q[HD], acc[HD];
+    {
+      const float4* qp = reinterpret_cast<const float4*>(p.Q + qpix * p.q_stride + p.q_choff + (hb + h) * HD);
+#pragma unroll
+      for (int i = 0; i < HD / 4; ++i) {
+        float4 v = qp[i];
+        q[4 * i] = v.x * p.scale; q[4 * i + 1] = v.y * p.scale; q[4 * i + 2] = v.z * p.scale; q[4 * i + 3] = v.w * p.scale;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HD; ++i) acc[i] = 0.f;
+    float mx = -INFINITY, den = 0.f;
+    const int a0 = max(0, t1 - p.l1), a1 = min(p.n1, t1 + p.r1);
+    const int b0 = max(0, t2 - p.l2), b1 = min(min(p.n2, p.clip2), t2 + p.r2);
+    for (int k1 = a0; k1 < a1; ++k1) {
+      const float* rowp = skv + ((k1 - k_lo) * p.n2) * TS + h * 2 * HD;
+      for (int k2 = b0; k2 < b1; ++k2) {
+        const float4* kp = reinterpret_cast<const float4*>(rowp + k2 * TS);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+          float4 kv = kp[i];
+          s = fmaf(q[4 * i], kv.x, s); s = fmaf(q[4 * i + 1], kv.y, s); s = fmaf(q[4 * i + 2], kv.z, s); s = fmaf(q[4 * i + 3], kv.w, s);
+        }
+        const float mn = fmaxf(mx, s);
+        const float corr = expf(mx - mn);
+        const float pw = expf(s - mn);
+        den = den * corr + pw;
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+          float4 vv = kp[HD / 4 + i];
+          acc[4 * i] = fmaf(pw, vv.x, acc[4 * i] * corr);
+          acc[4 * i + 1] = fmaf(pw, vv.y, acc[4 * i + 1] * corr);
+          acc[4 * i + 2] = fmaf(pw, vv.z, acc[4 * i + 2] * corr);
+          acc[4 * i + 3] = fmaf(pw, vv.w, acc[4 * i + 3] * corr);
+        }
+        mx = mn;
+      }
+    }
+    const float inv = 1.0f / den;
+    float4* op = reinterpret_cast<float4*>(p.O + qpix * p.o_stride + p.o_choff + (hb + h) * HD);
+#pragma unroll
+    for (int i = 0; i < HD / 4; ++i) op[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
+  }
 }
 
 // ---------------- HR tail: conv 3x3 64->1 over the HR mosaic + bicubic skip ------------------------------------------------
@@ -237,6 +322,30 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
   p.n1 = n1; p.n2 = n2; p.st1 = st1; p.st2 = st2; p.l1 = l1; p.r1 = r1; p.l2 = l2; p.r2 = r2; p.clip2 = clip2 > 0 ? clip2 : n2;
   p.scale = 1.0f / sqrtf((float)hd);
   p.total = (long long)ns0 * ns1 * ns2 * n1 * n2 * nheads;
+  // LDS-tiled path (hd 16, heads in pairs): stage the keys a tile of queries can see once; used when the staged tile fits
+  if (hd == 16 && nheads % 2 == 0 && !getenv("LFSR_ATTN_L1")) {
+    constexpr int HB = 2, TS = HB * 32 + 4;
+    int T1 = n1;                                            // whole sequence if it fits (EPIT: 5 x 32 tokens)
+    auto smem_for = [&](int t1) { int rows = t1 + l1 + r1 - 1; if (rows > n1) rows = n1; return (size_t)rows * n2 * TS * 4; };
+    while (T1 > 1 && smem_for(T1) > 96 * 1024) T1 = (T1 + 1) / 2;
+    if (smem_for(T1) <= 150 * 1024) {
+      const int ntile1 = (n1 + T1 - 1) / T1;
+      size_t smem = smem_for(T1);
+      static bool attr_set[64] = {};
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_window_attn_lds<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return LFSR_E_ARG;
+        attr_set[dev] = true;
+      }
+      int threads = T1 * n2 * HB;
+      threads = (threads + 63) / 64 * 64;
+      if (threads > 1024) threads = 1024;
+      dim3 grid((unsigned)((long long)ns0 * ns1 * ns2 * ntile1), (unsigned)(nheads / HB));
+      hipLaunchKernelGGL((k_window_attn_lds<16, 2>), grid, dim3(threads), smem, lfsr_stream(stream), p, T1, ntile1);
+      LFSR_CHECK_LAUNCH();
+      return LFSR_OK;
+    }
+  }
   unsigned grid = lfsr_blocks(p.total, 256);
   if (hd == 8) hipLaunchKernelGGL((k_window_attn<8>), dim3(grid), dim3(256), 0, lfsr_stream(stream), p);
   else hipLaunchKernelGGL((k_window_attn<16>), dim3(grid), dim3(256), 0, lfsr_stream(stream), p);
