@@ -294,6 +294,7 @@ size_t max_partial_floats(const lfsr_distgssr* c, int B, int h, int w) {
   size_t m = 0;
   auto up = [&](size_t v) { if (v > m) m = v; };
   up(lfsr_wgrad_partial_floats(npix, 9, 64, 64));
+  up((size_t)256 * 9 * 64 * 64);
   up(lfsr_wgrad_partial_floats(npix, 1, 64, 144));
   up(lfsr_wgrad_partial_floats(nlr, AA, 16, 64));
   up(lfsr_wgrad_partial_floats(nlr, AA, 16, 16));
@@ -404,9 +405,9 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   auto G = [&](const std::string& k) -> float* { return grads + c->slots.at(k).grad_off; };
   // weight gradient of a 3x3 conv: dW[tap][n][k] = sum_m g[m][n] * xin[conv3 src(m,tap)][k]
   auto wgrad3 = [&](const std::string& key, const float* xin, const float* g, int g_stride) -> int {
-    int r = lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_CONV3, g, g_stride, 0, xin, 64, 0, t.P[0], npix, 64, 64, 1, h, w, 9, st);
+    int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.P[0], nimg, h, w, st);
     if (r) return r;
-    return lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 9, 64), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, st);
+    return lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, st);
   };
   auto dgrad3 = [&](const float* dy, int dy_stride, const std::string& key, float* dx, const float* r1, const float* r2_unused, const float* mk, int mk_stride) -> int {
     (void)r2_unused;

@@ -48,6 +48,10 @@ int lfsr_wgrad_splits(int M, int ntaps, int K);
 size_t lfsr_wgrad_partial_floats(int M, int ntaps, int N, int K);
 int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff,
                       float* P, int M, int N, int K, int A, int h, int w, int ntaps, hipStream_t st);
+// halo-tile 3x3 conv weight gradient: partials P [lfsr_wgrad_conv3_blocks()][9][64][64], reduce with nsplit = that count
+int lfsr_wgrad_conv3_blocks(int n_img, int h, int w);
+int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P,
+                            int n_img, int h, int w, hipStream_t st);
 // c_valid < C: only the first c_valid input channels are written, with row length c_valid (init_conv's 9 taps)
 int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, float* dW, int O, int C, int T, int perm, int ch,
                       int accumulate, int c_valid, int chunk_mode, hipStream_t st);

@@ -97,6 +97,111 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs p) {
   }
 }
 
+
+// ---- 3x3 conv weight gradient, halo-tile form ------------------------------------------------------------------------------
+// dW[tap][n][k] = sum over pixels p of dY[p][n] * X[p + shift(tap)][k] (zero outside the view).  The gather form above re-reads
+// dY and the shifted X for every tap (9x the traffic).  Here a persistent 512-thread block walks 4-row x 32-column tiles: the
+// dY tile and the X halo are staged in LDS once and all 9 taps read X at shifted addresses.  The pixel index is the MFMA's K
+// dimension (two pixels per v_mfma_f32_32x32x2_f32).  Wave w owns the (n,k) quadrant w&3 for taps 0-4 (w<4) or 5-8 (w>=4):
+// 5 x 16 accumulator registers that persist across ALL tiles of the block, so each block writes ONE partial slab at the end.
+constexpr int WT_R = 4, WT_C = 32;
+constexpr int WX_PIX = (WT_R + 2) * (WT_C + 2);   // 204
+constexpr int WG_PIX = WT_R * WT_C;               // 128
+
+struct Wgrad3Args {
+  const float* G; int g_stride; int g_choff;
+  const float* X; int x_stride; int x_choff;
+  float* P;               // [gridDim.x][9][64][64]
+  int n_img, H, W, tiles_y, tiles_x;
+};
+
+__global__ __launch_bounds__(512) void k_wgrad_conv3_halo(Wgrad3Args p) {
+  extern __shared__ __attribute__((aligned(16))) float smw[];
+  float* sX = smw;                         // [WX_PIX][LDS_ROW]
+  float* sG = smw + WX_PIX * LDS_ROW;      // [WG_PIX][LDS_ROW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = tid & 15, r16 = tid >> 4;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int q = wave & 3, nq = q >> 1, kq = q & 1, t0 = (wave >> 2) ? 5 : 0, ntap = (wave >> 2) ? 4 : 5;
+  const int ntiles = p.n_img * p.tiles_y * p.tiles_x;
+
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 hx[7], hg[4];
+  auto load_tile = [&](int tile) {
+    int tx = tile % p.tiles_x; int qq = tile / p.tiles_x;
+    int ty = qq % p.tiles_y; int img = qq / p.tiles_y;
+    const int y0 = ty * WT_R, x0 = tx * WT_C;
+    const long long ib = (long long)img * p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      int pix = r16 + 32 * i;
+      hx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pix < WX_PIX) {
+        int r = pix / (WT_C + 2), c = pix - r * (WT_C + 2);
+        int yy = y0 + r - 1, xx = x0 + c - 1;
+        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+          hx[i] = *reinterpret_cast<const float4*>(p.X + (ib + (long long)yy * p.W + xx) * p.x_stride + p.x_choff + c16 * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int pix = r16 + 32 * i;
+      int r = pix / WT_C, c = pix - r * WT_C;
+      int yy = y0 + r, xx = x0 + c;
+      hg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yy < p.H && xx < p.W)
+        hg[i] = *reinterpret_cast<const float4*>(p.G + (ib + (long long)yy * p.W + xx) * p.g_stride + p.g_choff + c16 * 4);
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      int pix = r16 + 32 * i;
+      if (pix < WX_PIX) *reinterpret_cast<float4*>(sX + pix * LDS_ROW + c16 * 4) = hx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(sG + (r16 + 32 * i) * LDS_ROW + c16 * 4) = hg[i];
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);     // next tile flies under this tile's MFMAs
+    const float* gp = sG + nq * 32 + l31;
+    const float* xp = sX + kq * 32 + l31;
+#pragma unroll 4
+    for (int s = 0; s < WG_PIX / 2; ++s) {
+      const int pp = 2 * s + half, r = pp / WT_C, c = pp - r * WT_C;
+      const float a = gp[pp * LDS_ROW];
+      const float* xc = xp + ((r + 1) * (WT_C + 2) + (c + 1)) * LDS_ROW;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        if (t < ntap) {
+          const int tap = t0 + t, dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xc[(dy * (WT_C + 2) + dx) * LDS_ROW], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // D[row = n][col = k]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*half
+  float* out = p.P + (long long)blockIdx.x * 9 * 64 * 64;
+#pragma unroll
+  for (int t = 0; t < 5; ++t) {
+    if (t < ntap) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int n = nq * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        out[((long long)(t0 + t) * 64 + n) * 64 + kq * 32 + l31] = acc[t][r];
+      }
+    }
+  }
+}
+
 // sum partial slabs in split order and scatter to the PyTorch layout (O, C, T): inverse of k_pack_weight.
 // P2 (optional) is a second partial set with the same geometry (the vertical EPI pass shares its weights).
 __global__ __launch_bounds__(512) void k_wgrad_reduce(const float* __restrict__ P, int nsplit, const float* __restrict__ P2, int nsplit2,
@@ -194,6 +299,32 @@ int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_
   WG(IN_CHK_V, IN_SAME)   // EPIConv.2 vertical
 #undef WG
   return LFSR_E_ARG;
+}
+
+
+int lfsr_wgrad_conv3_blocks(int n_img, int h, int w) {
+  long long tiles = (long long)n_img * ((h + WT_R - 1) / WT_R) * ((w + WT_C - 1) / WT_C);
+  return (int)(tiles < 256 ? tiles : 256);
+}
+
+int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P,
+                            int n_img, int h, int w, hipStream_t st) {
+  if (!G || !X || !P || n_img <= 0 || h <= 0 || w <= 0 || ((g_stride | g_choff | x_stride | x_choff) & 3)) return LFSR_E_ARG;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  const int smem = (WX_PIX + WG_PIX) * LDS_ROW * 4;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_conv3_halo), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  Wgrad3Args p{};
+  p.G = G; p.g_stride = g_stride; p.g_choff = g_choff; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P;
+  p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + WT_R - 1) / WT_R; p.tiles_x = (w + WT_C - 1) / WT_C;
+  hipLaunchKernelGGL(k_wgrad_conv3_halo, dim3((unsigned)lfsr_wgrad_conv3_blocks(n_img, h, w)), dim3(512), smem, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
 }
 
 int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, float* dW, int O, int C, int T, int perm, int ch,

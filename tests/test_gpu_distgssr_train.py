@@ -15,6 +15,7 @@ from lfsr_amd.synth import synth_input, synth_state_dict
 from tests.helpers import GOLDEN, model_case
 
 pytestmark = pytest.mark.gpu
+torch.set_num_threads(8)   # the CPU reference legs run tiny convs: 100+ default threads on the GPU box only contend
 
 
 def load_plugin():
