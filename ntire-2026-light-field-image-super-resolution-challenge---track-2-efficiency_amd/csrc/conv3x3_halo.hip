@@ -12,6 +12,8 @@
 // LDS: 340 x 272 B (halo, rows padded to 68 floats -> conflict-free ds_read_b128) + 2 x 64 x 272 B = 124 KB,
 // one block per CU, 2 waves per SIMD.  The epilogue transposes the accumulators through the (then dead)
 // halo region so that stores/residual loads are 16 B per lane, 256 B contiguous per pixel.
+#include <stdlib.h>
+
 #include "lfsr_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,12 +41,16 @@ struct ConvArgs {
   const float* R2; int r2_stride; int r2_choff;
   const float* Mk; int mk_stride; int mk_choff; float mk_slope;   // backward: out *= (Mk > 0 ? 1 : mk_slope), before the residual adds
   int n_img, H, W, tiles_y, tiles_x;
+  int tile_begin, tile_count;   // tiles [tile_begin, tile_begin + tile_count) belong to this launch
   float slope;
 };
 
 // MASK = false: forward / plain dgrad (optional residuals R1, R2).  MASK = true: dgrad through a LeakyReLU, the operand
 // prefetched at tap 8 is the saved activation Mk instead of R1 (the two never occur together on the hot path).
-template <bool MASK>
+// NHALF = true: tail launch.  When the tile count is not a multiple of the CU count the last round would leave CUs idle for a
+// whole tile time; the leftover tiles are instead given to TWO blocks each, block (2t + nh) computing output channels
+// [32 nh, 32 nh + 32) of tile t (half the MFMAs, half the time), one tile per block.
+template <bool MASK, bool NHALF>
 __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
@@ -54,7 +60,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
   const int c16 = tid & 15, r16 = tid >> 4;
   const int half = lane >> 5, l31 = lane & 31;
   const int tiles_per_img = p.tiles_y * p.tiles_x;
-  const int ntiles = p.n_img * tiles_per_img;
+  const int ntiles = p.tile_begin + p.tile_count;   // end of this launch's tile range
+  const int nh = NHALF ? (int)(blockIdx.x & 1) : 0;
+  (void)tiles_per_img;
 
   // per-thread halo slots: slot i covers (pixel, 16-B chunk) = (tid + 512 i) >> 4, tid & 15
   int hoff[11];   // offset inside the image (pixels) relative to the tile origin, or INT_MIN if slot unused
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
   };
 
   const float* aBase = sA + ((wave + 1) * (TC + 2) + (l31 + 1)) * LROW + 4 * half;   // tap (0,0) position
-  const float* bBase = sB + l31 * LROW + 4 * half;
+  const float* bBase = sB + (nh * 32 + l31) * LROW + 4 * half;
   float* sO = sA + wave * 32 * LROW;   // epilogue transposition region (wave-private, inside the dead halo)
 
 #ifdef LFSR_CONV_DIAG
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
   float* dbgbuf = const_cast<float*>(p.R2);
   p.R2 = nullptr;
 #endif
-  int tile = blockIdx.x;
+  int tile = p.tile_begin + (NHALF ? (int)(blockIdx.x >> 1) : (int)blockIdx.x);
   int img, y0, x0;
   tile_origin(tile, img, y0, x0);
   float4 hv[11];
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     STAMP(4);   // halo LDS write + barrier
 
-    const int next = tile + gridDim.x;
+    const int next = NHALF ? ntiles : tile + (int)gridDim.x;
     const bool has_next = next < ntiles;
     int nimg = 0, ny0 = 0, nx0 = 0;
     if (has_next) tile_origin(next, nimg, ny0, nx0);
@@ -155,9 +163,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         const float* src = MASK ? p.Mk : p.R1;
         const int sst = MASK ? p.mk_stride : p.r1_stride, sco = MASK ? p.mk_choff : p.r1_choff;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          int pc = (lane >> 4) + 4 * i;
-          res[i] = (x0 + pc < p.W) ? *reinterpret_cast<const float4*>(src + (row_base + pc) * sst + sco + (lane & 15) * 4)
+        for (int i = 0; i < (NHALF ? 4 : 8); ++i) {
+          const int pc = NHALF ? (lane >> 3) + 8 * i : (lane >> 4) + 4 * i;
+          const int ch = NHALF ? nh * 8 + (lane & 7) : (lane & 15);
+          res[i] = (x0 + pc < p.W) ? *reinterpret_cast<const float4*>(src + (row_base + pc) * sst + sco + ch * 4)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
       if (tap == 0) {
         fa = *reinterpret_cast<const float4*>(aT);
         fb0 = *reinterpret_cast<const float4*>(bT);
-        fb1 = *reinterpret_cast<const float4*>(bT + 32 * LROW);
+        if (!NHALF) fb1 = *reinterpret_cast<const float4*>(bT + 32 * LROW);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -179,26 +188,35 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
         if (j < 7) {
           na = *reinterpret_cast<const float4*>(aT + 8 * (j + 1));
           nb0f = *reinterpret_cast<const float4*>(bT + 8 * (j + 1));
-          nb1f = *reinterpret_cast<const float4*>(bT + 32 * LROW + 8 * (j + 1));
+          if (!NHALF) nb1f = *reinterpret_cast<const float4*>(bT + 32 * LROW + 8 * (j + 1));
         } else if (tap < 8) {   // first fragments of the next tap (its slab was published by this tap's barrier)
           const int ndy = (tap + 1) / 3 - 1, ndx = (tap + 1) % 3 - 1;
           const float* naT = aBase + (ndy * (TC + 2) + ndx) * LROW;
           const float* nbT = bBase + ((tap + 1) % 3) * SB_FLOATS;
           na = *reinterpret_cast<const float4*>(naT);
           nb0f = *reinterpret_cast<const float4*>(nbT);
-          nb1f = *reinterpret_cast<const float4*>(nbT + 32 * LROW);
+          if (!NHALF) nb1f = *reinterpret_cast<const float4*>(nbT + 32 * LROW);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads first ...
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb1.w, acc1, 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs of this step
-        if (j < 7 || tap < 8) { fa = na; fb0 = nb0f; fb1 = nb1f; }
+        if (NHALF) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb0.x, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb0.y, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb0.z, acc0, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb0.w, acc0, 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // 3 DS reads first ...
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb0.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb0.y, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb0.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb0.w, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb1.w, acc1, 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // ... then the 8 MFMAs of this step
+        }
+        if (j < 7 || tap < 8) { fa = na; fb0 = nb0f; if (!NHALF) fb1 = nb1f; }
       }
     }
     STAMP(0);   // 9 taps
@@ -213,15 +231,15 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
       float v0 = acc0[r], v1 = acc1[r];
       v0 = v0 >= 0.f ? v0 : v0 * p.slope;
       v1 = v1 >= 0.f ? v1 : v1 * p.slope;
-      sO[pc * LROW + l31] = v0;
-      sO[pc * LROW + 32 + l31] = v1;
+      sO[pc * LROW + nh * 32 + l31] = v0;
+      if (!NHALF) sO[pc * LROW + 32 + l31] = v1;
     }
     __builtin_amdgcn_wave_barrier();
     if (yy < p.H) {
-      const int ch = lane & 15;
+      const int ch = NHALF ? nh * 8 + (lane & 7) : (lane & 15);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int pc = (lane >> 4) + 4 * i;
+      for (int i = 0; i < (NHALF ? 4 : 8); ++i) {
+        const int pc = NHALF ? (lane >> 3) + 8 * i : (lane >> 4) + 4 * i;
         if (x0 + pc < p.W) {
           float4 v = *reinterpret_cast<const float4*>(sO + pc * LROW + ch * 4);
           long long pix = row_base + pc;
@@ -269,8 +287,10 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
@@ -291,10 +311,23 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
     }
     ncu = cus[dev];
   }
-  // persistent: one 124-KB-LDS block per CU walks tiles blockIdx.x, +grid, ... (uniform cost, no queue needed)
-  unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);
-  if (mk) hipLaunchKernelGGL(k_conv3x3_halo<true>, dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  else hipLaunchKernelGGL(k_conv3x3_halo<false>, dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  LFSR_CHECK_LAUNCH();
+  // persistent: one 141-KB-LDS block per CU walks tiles blockIdx.x, +grid, ... (uniform cost, no queue needed).  Tiles beyond
+  // the last full round (L = ntiles % ncu) go to a second, channel-split launch when that halves the tail (2L <= ncu).
+  int tail = (int)(nblk % ncu);
+  if (nblk < ncu || 2 * tail > ncu || getenv("LFSR_CONV_NOTAIL")) tail = 0;
+  const int body = (int)nblk - tail;
+  if (body > 0) {
+    p.tile_begin = 0; p.tile_count = body;
+    unsigned grid = (unsigned)(body < ncu ? body : ncu);
+    if (mk) hipLaunchKernelGGL((k_conv3x3_halo<true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+    else hipLaunchKernelGGL((k_conv3x3_halo<false, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+    LFSR_CHECK_LAUNCH();
+  }
+  if (tail > 0) {
+    p.tile_begin = body; p.tile_count = tail;
+    if (mk) hipLaunchKernelGGL((k_conv3x3_halo<true, true>), dim3(2 * tail), dim3(512), SMEM_BYTES, st, p);
+    else hipLaunchKernelGGL((k_conv3x3_halo<false, true>), dim3(2 * tail), dim3(512), SMEM_BYTES, st, p);
+    LFSR_CHECK_LAUNCH();
+  }
   return LFSR_OK;
 }
