@@ -211,6 +211,10 @@ int lfsr_pointwise_fwd(const float* x, int x_stride, int x_choff, int cin, const
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
   p.M = M; p.N = N; p.Npad = npad32(N); p.A = 1; p.AA = 1; p.H = 1; p.W = 1; p.ntaps = 1; p.CH = N; p.slope = slope;
   hipStream_t st = lfsr_stream(stream);
+  if (M >= 2048 && !getenv("LFSR_NO_ROWGEMM")) {   // streaming kernel for the shapes it covers (fuse.0: 144 -> 64)
+    int rc = lfsr_rowgemm_launch(x, x_stride, x_choff, cin, w_packed, bias, nullptr, 0, 0, y, y_stride, y_choff, M, N, slope, st);
+    if (rc != LFSR_E_ARG) return rc;
+  }
   const bool two = (p.Npad % 64) == 0;
   switch (cin) {
     case 16: return launch_gemm<IN_SAME, OUT_SAME, 16, 1>(p, st);

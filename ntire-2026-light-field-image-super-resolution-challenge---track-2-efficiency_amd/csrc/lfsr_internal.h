@@ -43,6 +43,10 @@ int lfsr_init_gather9(const float* x, float* xg, int B, int A, int h, int w, hip
 int lfsr_add_inplace(float* a, const float* b, long long n, hipStream_t st);   // a += b
 int lfsr_pack_weight_chunkT(const float* w, float* out, int O, int C, int ch, int perm, hipStream_t st);
 
+// rowgemm.hip: persistent row-streaming GEMM with LDS-resident weights; LFSR_E_ARG = shape not covered (use the gather-GEMM)
+int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
+                        const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st);
+
 // wgrad.hip
 int lfsr_wgrad_splits(int M, int ntaps, int K);
 size_t lfsr_wgrad_partial_floats(int M, int ntaps, int N, int K);

@@ -1,0 +1,157 @@
+// Row-streaming GEMM with LDS-resident weights, fp32 MFMA: Y[m, n0:n0+NB] = act(X[m, 0:K] W^T (+bias)) (+res), for the 1x1 convs /
+// nn.Linear layers whose rows are plain pixel or token vectors (DistgSSR fuse.0 144->64, DistgSSR.py:99; the transformer
+// linears of EPIT.py:110-128 / LFT.py:188-246).  These layers sit near the HBM ridge (AI 16-40 FLOP/B), so the kernel is built
+// like a streaming op: a persistent 512-thread block keeps its NB x K weight panel in LDS for its whole life and walks 128-row
+// tiles; the next tile's rows are prefetched into registers (16-B loads, rows contiguous) while the current one runs its
+// MFMAs; one A image in LDS (rows padded by 4 floats: conflict-free ds_read_b128), two barriers per tile.
+// Against the generic gather-GEMM this removes the per-stage weight re-staging (a 128-row block re-read the whole panel) and
+// the 64-float K staging granularity.
+#include "gemm_gather_kernel.h"
+#include "lfsr_internal.h"
+
+namespace {
+
+struct RowGemmArgs {
+  const float* X; int x_stride; int x_choff;
+  const float* Wp;       // [N rows][K] (packed, k contiguous)
+  const float* bias;
+  const float* R1; int r1_stride; int r1_choff;
+  float* Y; int y_stride; int y_choff;
+  long long M; int N;
+  float slope;
+};
+
+template <int K, int NB, int BMR>
+__global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
+  constexpr int LR = K + 4;                 // LDS row stride (floats)
+  constexpr int NTH = BMR * 4;              // BMR/32 row groups x 2 column halves x 64 lanes
+  constexpr int NT = NB / 64;               // 32-col tiles per wave (waves: 4 row groups x 2 column halves)
+  constexpr int CPR = K / 4;                // 16-B chunks per row
+  constexpr int AL = (BMR * CPR + NTH - 1) / NTH;   // A chunks per thread
+  constexpr int WL = (NB * CPR + NTH - 1) / NTH;
+  extern __shared__ __attribute__((aligned(16))) float smr[];
+  float* sW = smr;                          // [NB][LR]
+  float* sA = smr + NB * LR;                // [BMR][LR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int rg = wave % (BMR / 32), ng = wave / (BMR / 32);
+  const int n0 = blockIdx.y * NB;
+  const long long ntiles = (p.M + BMR - 1) / BMR;
+
+  // weight panel (rows beyond N are zero in the packed buffer's padding only up to Npad32: guard)
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    int idx = tid + NTH * i;
+    if (idx < NB * CPR) {
+      int r = idx / CPR, c = idx - r * CPR;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + r < p.N) v = *reinterpret_cast<const float4*>(p.Wp + (long long)(n0 + r) * K + c * 4);
+      *reinterpret_cast<float4*>(sW + r * LR + c * 4) = v;
+    }
+  }
+
+  float4 ra[AL];
+  auto prefetch = [&](long long tile) {
+    const long long m0 = tile * BMR;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      int idx = tid + NTH * i;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < BMR * CPR) {
+        int r = idx / CPR, c = idx - r * CPR;
+        if (m0 + r < p.M) ra[i] = *reinterpret_cast<const float4*>(p.X + (m0 + r) * p.x_stride + p.x_choff + c * 4);
+      }
+    }
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+  const float* aRow = sA + (rg * 32 + l31) * LR + 4 * half;
+  const float* bRow = sW + (ng * (NB / 2) + l31) * LR + 4 * half;
+  for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      int idx = tid + NTH * i;
+      if (idx < BMR * CPR) { int r = idx / CPR, c = idx - r * CPR; *reinterpret_cast<float4*>(sA + r * LR + c * 4) = ra[i]; }
+    }
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 6
+    for (int j = 0; j < K / 8; ++j) {
+      float4 a = *reinterpret_cast<const float4*>(aRow + 8 * j);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float4 b = *reinterpret_cast<const float4*>(bRow + t * 32 * LR + 8 * j);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    // epilogue straight from the accumulators: a store instruction covers 32 consecutive channels of two rows
+    const long long m0 = tile * BMR;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = n0 + ng * (NB / 2) + t * 32 + l31;
+        if (n >= p.N) continue;
+        float v = acc[t][r];
+        if (p.bias) v += p.bias[n];
+        v = v >= 0.f ? v : v * p.slope;
+        if (p.R1) v += p.R1[m * p.r1_stride + p.r1_choff + n];
+        p.Y[m * p.y_stride + p.y_choff + n] = v;
+      }
+    }
+    __syncthreads();   // everyone is done with sA before the next tile's rows overwrite it
+  }
+}
+
+template <int K, int NB, int BMR>
+int launch_rowgemm(const RowGemmArgs& p, hipStream_t st) {
+  constexpr int smem = (NB + BMR) * (K + 4) * 4;
+  constexpr int per_cu = smem <= 78 * 1024 ? 2 : 1;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<K, NB, BMR>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  const long long ntiles = (p.M + BMR - 1) / BMR;
+  const int nby = (p.N + NB - 1) / NB;
+  int gx = 256 * per_cu / nby;              // fill every CU with the blocks its LDS admits
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = (int)ntiles;
+  hipLaunchKernelGGL((k_rowgemm<K, NB, BMR>), dim3((unsigned)gx, (unsigned)nby), dim3(BMR * 4), smem, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+}  // namespace
+
+// returns LFSR_E_ARG when the shape is not covered (caller falls back to the gather-GEMM)
+int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
+                        const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st) {
+  if ((x_stride | x_choff) & 3 || N % 32) return LFSR_E_ARG;
+  RowGemmArgs p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.bias = bias; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
+  p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = slope;
+  // 64-row tiles, 64-column panels: <= 76 KB of LDS -> two 256-thread blocks per CU, which is what keeps HBM loads in flight
+  // while the other block runs its MFMAs
+  if (N % 64) return LFSR_E_ARG;
+  switch (K) {
+    case 64: return launch_rowgemm<64, 64, 64>(p, st);
+    case 128: return launch_rowgemm<128, 64, 64>(p, st);
+    case 144: return launch_rowgemm<144, 64, 64>(p, st);
+    default: return LFSR_E_ARG;
+  }
+}

@@ -362,6 +362,10 @@ int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const fl
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
   p.M = (int)M; p.N = N; p.Npad = npad32(N); p.A = 1; p.AA = 1; p.H = 1; p.W = 1; p.ntaps = 1; p.CH = N; p.slope = slope;
   hipStream_t st = lfsr_stream(stream);
+  if (M >= 2048 && !getenv("LFSR_NO_ROWGEMM")) {
+    int rc = lfsr_rowgemm_launch(x, x_stride, x_choff, cin, w_packed, bias, res, res_stride, res_choff, y, y_stride, y_choff, M, N, slope, st);
+    if (rc != LFSR_E_ARG) return rc;
+  }
   const bool two = (p.Npad % 64) == 0;
   switch (cin) {
     case 64: return two ? launch_gemm<IN_SAME, OUT_SAME, 64, 2>(p, st) : launch_gemm<IN_SAME, OUT_SAME, 64, 1>(p, st);
