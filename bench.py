@@ -182,7 +182,7 @@ def main():
                        "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "k_conv3x3_halo<false> (per-view 3x3 64->64, persistent halo-tile kernel, fp32 MFMA 32x32x2)",
+                         "kernel": "k_conv3x3_halo (per-view 3x3 64->64, persistent halo-tile kernel + channel-split tail launch, fp32 MFMA 32x32x2); duration = both launches of one conv op",
                          "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_ms, "launches_timed": conv_n},
             "model_tflops": FLOP_PER_PATCH * world * BATCH * args.steps / el / 1e12,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
