@@ -393,6 +393,7 @@ int lfsr_distgssr_forward_train(lfsr_distgssr* c, const float* x, float* out, in
 int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, int B, int h, int w, void* workspace, size_t workspace_bytes,
                            float* grads, size_t n_grads, void* stream) {
   if (!c || !x || !dout || !workspace || !grads || B <= 0 || h <= 0 || w <= 0 || !c->finalized || n_grads != c->n_params) return LFSR_E_ARG;
+  if (!(c->A & 1)) return LFSR_E_ARG;   // the EPI data gradient's line-shift gathers assume the symmetric padding of odd angRes
   TrainWs t;
   train_layout(c, B, h, w, (float*)workspace, t);
   if (workspace_bytes < t.total * sizeof(float)) return LFSR_E_WS;

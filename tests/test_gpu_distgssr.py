@@ -249,3 +249,30 @@ def test_distgssr_large_view_patch():
     y = rt.forward(dev(x)).cpu().numpy()
     ref = O.distgssr_forward(x, sd, A, s)
     assert np.abs(y - ref).max() < ATOL
+
+
+@pytest.mark.parametrize("A,s,h,w,B", [(7, 2, 6, 6, 1), (5, 3, 8, 8, 2), (2, 2, 6, 6, 1)])
+def test_distgssr_other_angres_and_scales(A, s, h, w, B):
+    """angular resolutions beyond the fused-EPI fast path (A = 7: gather-GEMM EPI; A = 2: even A, general column arithmetic of
+    the 1xA^2 conv) and scale 3, against the oracle (weights regenerated for the matching state_dict shapes)"""
+    from lfsr_amd.synth import synth_state_dict
+    AA = A * A
+    spec = [("init_conv.weight", (64, 1, 3, 3))]
+    for g in range(4):
+        for b in range(4):
+            p = f"disentg.Group.{g}.Block.{b}."
+            spec += [(p + "SpaConv.0.weight", (64, 64, 3, 3)), (p + "SpaConv.2.weight", (64, 64, 3, 3)),
+                     (p + "AngConv.0.weight", (16, 64, A, A)), (p + "AngConv.2.weight", (AA * 16, 16, 1, 1)),
+                     (p + "EPIConv.0.weight", (32, 64, 1, AA)), (p + "EPIConv.2.weight", (A * 32, 32, 1, 1)),
+                     (p + "fuse.0.weight", (64, 144, 1, 1)), (p + "fuse.2.weight", (64, 64, 3, 3))]
+        spec.append((f"disentg.Group.{g}.conv.weight", (64, 64, 3, 3)))
+    spec += [("disentg.conv.weight", (64, 64, 3, 3)), ("upsample.0.weight", (64 * s * s, 64, 1, 1)), ("upsample.0.bias", (64 * s * s,)),
+             ("upsample.2.weight", (1, 64, 1, 1))]
+    sd = synth_state_dict(spec, seed=3)
+    x = synth_input((B, 1, A * h, A * w), seed=7)
+    rt = capi.DistgSSRRuntime(A, s)
+    rt.load_state([(k, dev(v)) for k, v in sd.items()], torch.device("cuda", 0))
+    y = rt.forward(dev(x)).cpu().numpy()
+    ref = O.distgssr_forward(x, sd, A, s)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < ATOL
