@@ -204,6 +204,9 @@ int lfsr_lft_position_fwd(float* spa_pe, float* ang_pe, int A, int h, int w, int
  * then LeakyReLU(slope) -> 3x3 conv 64->1 (zero pad 1 over the whole mosaic) + per-view bicubic skip of x_lr. */
 int lfsr_upsample_ps_fwd(const float* f, int f_stride, int f_choff, const float* w_packed, float* hr, int B, int A, int h, int w,
                          int s, void* stream);
+/* both steps fused (s in {2,4}): the (B,64,A h s,A w s) intermediate never exists.  w0_packed as for lfsr_upsample_ps_fwd. */
+int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const float* w0_packed, const float* w3, const float* x_lr, float* out,
+                     int B, int A, int h, int w, int s, float slope, void* stream);
 int lfsr_hr_tail_fwd(const float* hr, const float* w3, const float* x_lr, float* out, int B, int A, int h, int w, int s,
                      float slope, void* stream);
 

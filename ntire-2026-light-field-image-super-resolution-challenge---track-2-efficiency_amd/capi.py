@@ -78,6 +78,7 @@ SIGNATURES = {
     "lfsr_window_attn_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                    C.c_longlong, C.c_longlong, C.c_longlong, c_i, c_i, C.c_longlong, C.c_longlong, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_upsample_ps_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_up_tail_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_hr_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_epit_create": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i]),
     "lfsr_epit_destroy": (None, [c_p]),

@@ -1,6 +1,8 @@
 // Host driver for the EPIT forward (get_model.forward, model/SR/EPIT.py:51-71; AltFilter :144-161; BasicTrans :110-128)
 // on VCL buffers.  Tokens are VCL pixels; the horizontal / vertical EPI passes differ only in the strides handed to the
 // attention kernel, so none of the reference's six `rearrange` copies per AltFilter exists here.
+#include <stdlib.h>
+
 #include "param_table.h"
 
 struct lfsr_epit {
@@ -130,8 +132,12 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
     }
     cur = o;
   }
-  RC(lfsr_upsample_ps_fwd(cur, 64, 0, P.w("upsampling.0.weight"), HR, B, A, h, w, c->s, stream));
-  RC(lfsr_hr_tail_fwd(HR, P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
+  if ((c->s == 2 || c->s == 4) && !getenv("LFSR_NO_UPTAIL")) {
+    RC(lfsr_up_tail_fwd(cur, 64, 0, P.w("upsampling.0.weight"), P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
+  } else {
+    RC(lfsr_upsample_ps_fwd(cur, 64, 0, P.w("upsampling.0.weight"), HR, B, A, h, w, c->s, stream));
+    RC(lfsr_hr_tail_fwd(HR, P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
+  }
 #undef RC
   return LFSR_OK;
 }

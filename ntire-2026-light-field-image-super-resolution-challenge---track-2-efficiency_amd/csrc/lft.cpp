@@ -2,6 +2,8 @@
 // Tokens are VCL pixels: the angular transformer's sequences (25 views at one (y,x)) and the spatial transformer's
 // (32x32 positions of one view) are just two stride sets for the same attention kernel; the 5x5 window mask
 // (LFT.py:161-174, rebuilt on the CPU per call upstream) is a predicate, so 25 keys per query are visited, not 1024.
+#include <stdlib.h>
+
 #include "param_table.h"
 
 struct lfsr_lft {
@@ -142,8 +144,12 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
     RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(sp + "linear.0.weight"), nullptr, last ? BUF0 : nullptr, 64, 0, s_out, 64, 0, npix, 64, 1.0f, stream));
     cur = s_out;
   }
-  RC(lfsr_upsample_ps_fwd(cur, 64, 0, P.w("upsampling.0.weight"), HR, B, A, h, w, c->s, stream));
-  RC(lfsr_hr_tail_fwd(HR, P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
+  if ((c->s == 2 || c->s == 4) && !getenv("LFSR_NO_UPTAIL")) {
+    RC(lfsr_up_tail_fwd(cur, 64, 0, P.w("upsampling.0.weight"), P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
+  } else {
+    RC(lfsr_upsample_ps_fwd(cur, 64, 0, P.w("upsampling.0.weight"), HR, B, A, h, w, c->s, stream));
+    RC(lfsr_hr_tail_fwd(HR, P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
+  }
 #undef RC
   return LFSR_OK;
 }

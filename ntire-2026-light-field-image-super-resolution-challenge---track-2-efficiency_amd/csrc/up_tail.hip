@@ -1,0 +1,210 @@
+// Fused up-sampling tail of EPIT / LFT (EPIT.py:44-49,70; LFT.py:52-57,94-96), fp32:
+//   out = conv3x3_{64->1}( LeakyReLU( PixelShuffle_s( conv1x1_{64 -> 64 s^2}(F) ) ) )  +  per-view bicubic_s(x_lr)
+// over the whole HR SAI mosaic (zero pad 1, crossing view borders exactly as the reference does).
+// The two-kernel form materialises the (B, 64, A h s, A w s) tensor -- 105 MB per patch, written once and read 9x from L1 --
+// and ran at 0.7 TB/s.  Here it never exists: a 512-thread block owns a 4 x 32 tile of LR mosaic pixels (+1 halo, 204 px);
+// for each chunk of CC = 64/s^2 feature channels it (1) runs the 1x1 conv for the 204 px x 64 columns (CC channels x s^2
+// sub-positions) on fp32 MFMA from the LDS-resident F tile, (2) LeakyReLU's the result into LDS, (3) lets every thread add
+// the 9-tap x CC-channel contribution to its 4 HR outputs (the HR neighbour (Y+dy, X+dx) is sub-position ((Y+dy)%s, (X+dx)%s)
+// of LR pixel ((Y+dy)/s, (X+dx)/s)).  Halo pixels outside the mosaic hold F = 0, hence U = 0 = the conv's zero padding
+// (there is no bias).  Weight chunks are prefetched through registers into a double-buffered LDS slab.
+#include "gemm_gather_kernel.h"
+#include "lfsr_internal.h"
+
+namespace {
+
+constexpr int UT_Y = 4, UT_X = 32;
+constexpr int UT_PIX = (UT_Y + 2) * (UT_X + 2);   // 204
+constexpr int UT_ROWS = 224;                      // padded to 7 MFMA row tiles
+
+struct UpTailArgs {
+  const float* F; int f_stride; int f_choff;     // VCL features
+  const float* W0p;                              // packed [64 s^2][64], row n' = ij*64 + c  (lfsr_pack_conv_weight perm 1, ch 64)
+  const float* W3;                               // (1,64,3,3)
+  const float* Xlr;                              // (B,1,A*h,A*w)
+  float* Out;                                    // (B,1,A*h*s,A*w*s)
+  int B, A, h, w;
+  int tiles_y, tiles_x;
+  float slope;
+};
+
+__device__ __forceinline__ void ut_cubic(float t, float c[4]) {
+  const float a = -0.75f;
+  float x1 = t + 1.f, x2 = t, x3 = 1.f - t, x4 = 2.f - t;
+  c[0] = ((a * x1 - 5.f * a) * x1 + 8.f * a) * x1 - 4.f * a;
+  c[1] = ((a + 2.f) * x2 - (a + 3.f)) * x2 * x2 + 1.f;
+  c[2] = ((a + 2.f) * x3 - (a + 3.f)) * x3 * x3 + 1.f;
+  c[3] = ((a * x4 - 5.f * a) * x4 + 8.f * a) * x4 - 4.f * a;
+}
+
+template <int S>
+__global__ __launch_bounds__(512) void k_up_tail(UpTailArgs p) {
+  constexpr int S2 = S * S, CC = 64 / S2, NCH = 64 / CC;   // channels per chunk, number of chunks
+  extern __shared__ __attribute__((aligned(16))) float smu[];
+  float* sF = smu;                                   // [UT_ROWS][LDS_ROW]
+  float* sU = sF + UT_ROWS * LDS_ROW;                // [UT_ROWS][LDS_ROW]   U chunk, column n = dc*S2 + ij
+  float* sW = sU + UT_ROWS * LDS_ROW;                // [2][64][LDS_ROW]
+  float* sW3 = sW + 2 * 64 * LDS_ROW;                // [64][9]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = tid & 15, r16 = tid >> 4;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int Hm = p.A * p.h, Wm = p.A * p.w, HW = p.h * p.w;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+  const int Y0 = ty * UT_Y, X0 = tx * UT_X;          // LR mosaic origin of the tile
+
+  // ---- stage the F halo tile (zero outside the mosaic), w3, and weight chunk 0 ------------------------------------------
+  for (int i = tid; i < 64 * 9; i += 512) sW3[i] = p.W3[i];
+  for (int idx = tid; idx < UT_ROWS * 16; idx += 512) {
+    int px = idx >> 4, ch = idx & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (px < UT_PIX) {
+      int ly = px / (UT_X + 2), lx = px - ly * (UT_X + 2);
+      int Ym = Y0 + ly - 1, Xm = X0 + lx - 1;
+      if (Ym >= 0 && Ym < Hm && Xm >= 0 && Xm < Wm) {
+        int u = Ym / p.h, y = Ym - u * p.h, vv = Xm / p.w, x = Xm - vv * p.w;
+        long long pix = ((long long)b * p.A * p.A + u * p.A + vv) * HW + (long long)y * p.w + x;
+        v = *reinterpret_cast<const float4*>(p.F + pix * p.f_stride + p.f_choff + ch * 4);
+      }
+    }
+    *reinterpret_cast<float4*>(sF + px * LDS_ROW + ch * 4) = v;
+  }
+  // weight chunk cc: LDS row (dc*S2 + ij) <- packed row (ij*64 + cc*CC + dc)
+  auto wrow = [&](int cc, int r) -> const float* { int dc = r / S2, ij = r - dc * S2; return p.W0p + ((long long)(ij * 64 + cc * CC + dc)) * 64; };
+  float4 rw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow(0, r16 + 32 * i) + c16 * 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(sW + (r16 + 32 * i) * LDS_ROW + c16 * 4) = rw[i];
+  __syncthreads();
+
+  // this thread's 4 HR outputs: o = tid + 512 i  -> local HR (Yl, Xl) in the tile's (UT_Y*S) x (UT_X*S) window
+  float oacc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int HRW = UT_X * S;
+  constexpr int NOUT = UT_Y * S * HRW;            // HR outputs of the tile (2048 for s = 4, 512 for s = 2)
+
+  for (int cc = 0; cc < NCH; ++cc) {
+    const float* sWc = sW + (cc & 1) * 64 * LDS_ROW;
+    if (cc + 1 < NCH) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow(cc + 1, r16 + 32 * i) + c16 * 4);
+    }
+    // ---- (1) U[px][n] = sum_k F[px][k] W[n][k] : 7 row tiles x 2 column tiles over 8 waves -----------------------------------
+    for (int item = wave; item < 14; item += 8) {
+      const int rt = item >> 1, ct = item & 1;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* aRow = sF + (rt * 32 + l31) * LDS_ROW + 4 * half;
+      const float* bRow = sWc + (ct * 32 + l31) * LDS_ROW + 4 * half;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float4 a = *reinterpret_cast<const float4*>(aRow + 8 * j);
+        float4 bq = *reinterpret_cast<const float4*>(bRow + 8 * j);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, acc, 0, 0, 0);
+      }
+      // (2) LeakyReLU -> sU ; D layout: column n = lane&31, row = (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int px = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r];
+        sU[px * LDS_ROW + ct * 32 + l31] = v >= 0.f ? v : v * p.slope;
+      }
+    }
+    if (cc + 1 < NCH) {
+      float* sWn = sW + ((cc + 1) & 1) * 64 * LDS_ROW;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(sWn + (r16 + 32 * i) * LDS_ROW + c16 * 4) = rw[i];
+    }
+    __syncthreads();
+    // ---- (3) 3x3 HR conv contribution of this chunk's CC channels ---------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = tid + 512 * i;
+      if (o >= NOUT) break;
+      const int Yl = o / HRW, Xl = o - Yl * HRW;
+      float a = oacc[i];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int Yh = Yl + ky - 1 + S;               // +S: halo row offset in HR units (never negative)
+        const int ly = Yh / S, sy = Yh - ly * S;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int Xh = Xl + kx - 1 + S;
+          const int lx = Xh / S, sx = Xh - lx * S;
+          const float* up = sU + (ly * (UT_X + 2) + lx) * LDS_ROW + sy * S + sx;
+          const float* wp = sW3 + (cc * CC) * 9 + ky * 3 + kx;
+#pragma unroll
+          for (int dc = 0; dc < CC; ++dc) a = fmaf(up[dc * S2], wp[dc * 9], a);
+        }
+      }
+      oacc[i] = a;
+    }
+    __syncthreads();
+  }
+
+  // ---- + per-view bicubic skip, store -------------------------------------------------------------------------------------------
+  const int Hs = Hm * S, Ws = Wm * S;
+  const float rs = 1.0f / (float)S;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = tid + 512 * i;
+    if (o >= NOUT) break;
+    const int Yl = o / HRW, Xl = o - Yl * HRW;
+    const int Y = Y0 * S + Yl, X = X0 * S + Xl;
+    if (Y >= Hs || X >= Ws) continue;
+    const int u = Y / (p.h * S), yl = Y - u * p.h * S, v = X / (p.w * S), xl = X - v * p.w * S;
+    const float sy = ((float)yl + 0.5f) * rs - 0.5f, sx = ((float)xl + 0.5f) * rs - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sx);
+    float cy[4], cx[4];
+    ut_cubic(sy - fy, cy);
+    ut_cubic(sx - fx, cx);
+    const float* img = p.Xlr + (long long)b * Hm * Wm + (long long)(u * p.h) * Wm + v * p.w;
+    float up = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int iy = min(max((int)fy - 1 + q, 0), p.h - 1);
+      float rowv = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int ix = min(max((int)fx - 1 + j, 0), p.w - 1);
+        rowv = fmaf(cx[j], img[(long long)iy * Wm + ix], rowv);
+      }
+      up = fmaf(cy[q], rowv, up);
+    }
+    p.Out[((long long)b * Hs + Y) * Ws + X] = oacc[i] + up;
+  }
+}
+
+}  // namespace
+
+extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const float* w0_packed, const float* w3, const float* x_lr, float* out,
+                                int B, int A, int h, int w, int s, float slope, void* stream) {
+  if (!f || !w0_packed || !w3 || !x_lr || !out || B <= 0 || A <= 0 || h <= 0 || w <= 0 || (s != 2 && s != 4)) return LFSR_E_ARG;
+  if (f_stride < f_choff + 64 || (f_stride | f_choff) & 3) return LFSR_E_ARG;
+  const int smem = (2 * UT_ROWS * LDS_ROW + 2 * 64 * LDS_ROW + 64 * 9) * 4;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  UpTailArgs p{};
+  p.F = f; p.f_stride = f_stride; p.f_choff = f_choff; p.W0p = w0_packed; p.W3 = w3; p.Xlr = x_lr; p.Out = out;
+  p.B = B; p.A = A; p.h = h; p.w = w; p.slope = slope;
+  p.tiles_y = (A * h + UT_Y - 1) / UT_Y; p.tiles_x = (A * w + UT_X - 1) / UT_X;
+  long long grid = (long long)B * p.tiles_y * p.tiles_x;
+  if (grid > 0x7fffffffLL) return LFSR_E_ARG;
+  if (s == 2) hipLaunchKernelGGL((k_up_tail<2>), dim3((unsigned)grid), dim3(512), smem, lfsr_stream(stream), p);
+  else hipLaunchKernelGGL((k_up_tail<4>), dim3((unsigned)grid), dim3(512), smem, lfsr_stream(stream), p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
