@@ -24,6 +24,8 @@ int lfsr_lft_create(lfsr_lft** out, int A, int scale, int n_layer, int channels)
   for (int b = 0; b < n_layer; ++b) {
     std::string sp = "altblock." + std::to_string(b) + ".spa_trans.";
     P.add(sp + "MLP.weight", 128, 64, 9);                       // (128, 576) == (128, 64, 3, 3): unfold order is c*9 + tap
+    P.add(sp + "MLP.weight#lo", 64, 64, 9);                     // the same weights as two 64-output 3x3 convs for the halo-tile kernel
+    P.add(sp + "MLP.weight#hi", 64, 64, 9);
     P.add(sp + "norm.weight", 128, 1, 1, 0, 0, true);
     P.add(sp + "norm.bias", 128, 1, 1, 0, 0, true);
     P.add(sp + "attention.in_proj_weight", 384, 128, 1);
@@ -55,7 +57,13 @@ int lfsr_lft_set_packed(lfsr_lft* c, void* packed, size_t bytes) { if (!c) retur
 int lfsr_lft_load_param(lfsr_lft* c, const char* key, const float* data, size_t numel, void* stream) {
   if (!c) return LFSR_E_ARG;
   c->finalized = false;
-  return c->P.load(key, data, numel, stream);
+  int rc = c->P.load(key, data, numel, stream);
+  std::string k(key ? key : "");
+  if (!rc && k.size() > 10 && k.compare(k.size() - 10, 10, "MLP.weight") == 0) {
+    rc = c->P.load((k + "#lo").c_str(), data, (size_t)64 * 576, stream);
+    if (!rc) rc = c->P.load((k + "#hi").c_str(), data + 64 * 576, (size_t)64 * 576, stream);
+  }
+  return rc;
 }
 int lfsr_lft_finalize(lfsr_lft* c, void* stream) {
   (void)stream;
@@ -127,7 +135,8 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
     // ---- SpaTrans (LFT.py:188-203): tokens = the h*w positions of one view; E = 128, 8 heads of 16, 5x5 window --------
     std::string sp = "altblock." + std::to_string(b) + ".spa_trans.";
     float* s_out = (a_out == Pb) ? Qb : Pb;
-    RC(lfsr_conv3x3_n_fwd(a_out, 64, 0, P.w(sp + "MLP.weight"), T, 128, 0, nimg, h, w, 128, 1.0f, stream));            // unfold + MLP (tokens)
+    RC(lfsr_conv3x3_fwd(a_out, 64, 0, P.w(sp + "MLP.weight#lo"), T, 128, 0, nullptr, 0, 0, nullptr, 0, 0, nimg, h, w, 1.0f, stream));   // unfold + MLP (tokens),
+    RC(lfsr_conv3x3_fwd(a_out, 64, 0, P.w(sp + "MLP.weight#hi"), T, 128, 64, nullptr, 0, 0, nullptr, 0, 0, nimg, h, w, 1.0f, stream));  // as two 64-output convs
     RC(lfsr_conv3x3_n_fwd(SPOS, 64, 0, P.w(sp + "MLP.weight"), SPE, 128, 0, 1, h, w, 128, 1.0f, stream));              // same embedding of the PE map
     RC(lfsr_layernorm_fwd(T, 128, 0, SPE, 128, HW, 1, P.w(sp + "norm.weight"), P.w(sp + "norm.bias"), TN, 128, 0, npix, 128, 1e-5f, stream));
     const float* Ws = P.w(sp + "attention.in_proj_weight");
