@@ -2,6 +2,8 @@
 // Every data gradient of DistgSSR is again a gather-GEMM (the transposed index map of a gather is a gather), with the
 // weights packed transposed (lfsr_pack_weight_T / _chunkT) and two epilogue extras: the LeakyReLU' mask taken from the
 // saved forward activation, and in-place accumulation into the gradient buffer (R1 aliasing Y).
+#include <stdlib.h>
+
 #include "gemm_gather_kernel.h"
 #include "lfsr_internal.h"
 
@@ -173,6 +175,12 @@ int lfsr_conv3x3_bwd_data(const float* dy, int dy_stride, int dy_choff, const fl
                           const float* r1, int r1_stride, int r1_choff, const float* mk, int mk_stride, int mk_choff, float mk_slope,
                           int n_img, int h, int w, hipStream_t st) {
   const bool al = !((dy_stride | dy_choff | dx_stride | dx_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!mk || !((mk_stride | mk_choff) & 3));
+  {
+    const char* sel = getenv("LFSR_CONV3X3");
+    if (al && !(sel && (sel[0] == 'h' || sel[0] == 'g')))
+      return lfsr_conv3x3_wino_launch(dy, dy_stride, dy_choff, wT_packed + LFSR_CONV3_DIRECT_FLOATS, wT_packed, dx, dx_stride, dx_choff, r1, r1_stride, r1_choff,
+                                      nullptr, 0, 0, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, 1.0f, st);
+  }
   if (al)
     return lfsr_conv3x3_halo_launch(dy, dy_stride, dy_choff, wT_packed, dx, dx_stride, dx_choff, r1, r1_stride, r1_choff, nullptr, 0, 0,
                                     mk, mk_stride, mk_choff, mk_slope, n_img, h, w, 1.0f, st);

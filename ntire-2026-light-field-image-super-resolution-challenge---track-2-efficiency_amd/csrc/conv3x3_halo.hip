@@ -331,3 +331,31 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
   }
   return LFSR_OK;
 }
+
+// channel-split launch over tiles [tile_begin, tile_begin + tile_count) only: the tail of the Winograd kernel (conv3x3_wino.hip)
+int lfsr_conv3x3_halo_tail_launch(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
+                                  const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                                  const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                                  int n_img, int h, int w, float slope, int tile_begin, int tile_count, hipStream_t st) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_halo<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  if (tile_count <= 0) return LFSR_OK;
+  ConvArgs p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed;
+  p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
+  p.R1 = r1; p.r1_stride = r1_stride; p.r1_choff = r1_choff; p.R2 = r2; p.r2_stride = r2_stride; p.r2_choff = r2_choff;
+  p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
+  p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + TR - 1) / TR; p.tiles_x = (w + TC - 1) / TC; p.slope = slope;
+  p.tile_begin = tile_begin; p.tile_count = tile_count;
+  if (mk) hipLaunchKernelGGL((k_conv3x3_halo<true, true>), dim3(2 * tile_count), dim3(512), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((k_conv3x3_halo<false, true>), dim3(2 * tile_count), dim3(512), SMEM_BYTES, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

@@ -1,0 +1,427 @@
+// Per-view 3x3 conv, zero pad 1, 64 -> 64 channels, VCL layout -- Winograd F(2x2, 3x3) on the fp32 MFMA pipe.
+// Reference: the MacPI convs "k3, dilation A, padding A" of model/SR/DistgSSR.py:22,47,64,79-83,101 (per-view 3x3 in VCL),
+// EPIT.py:24-32,136-142 / LFT.py:36-46 (Conv3d(1,3,3)).
+//
+//   Y = At [ sum_c (G g G^t) . (Bt d B) ] A     per 2x2 output tile, d = its 4x4 input patch, 16 transform positions p = (xi, nu)
+//
+// The 16 positions are 16 independent [tiles x 64] x [64 x 64] GEMMs -> 2.25x fewer MFMA flops than the 9-tap direct form,
+// all arithmetic exact fp32 (products and sums; the transform coefficients are 0, +-1, +-1/2).
+//
+// Persistent 512-thread block (8 waves) per CU walks 8-row x 32-column output tiles (same tiling as conv3x3_halo.hip):
+//  * the (8+2) x (32+2) input halo sits in LDS once, 64 floats per pixel, 16-B chunks XOR-swizzled by (pixel>>1) so that
+//    the stride-2-pixel patch reads of 32 Winograd tiles are conflict-free ds_read_b128;
+//  * wave (mg, xi): mg = 4-row half of the tile = 2 x 16 = 32 Winograd tiles (the 32 A-rows of v_mfma_f32_32x32x2_f32),
+//    xi = one row of the 4x4 transform domain.  Per 8-channel stage it reads 2 patch rows x 4 columns (8 x b128), forms the
+//    four V[xi][nu] fragments in registers (8 float4 add/sub), and runs 4 positions x 2 N-tiles x 4 = 32 MFMAs
+//    (8 accumulators = 128 registers);
+//  * transformed weights U stream through a 3-deep LDS ring of 16-KB units (stage j, N-tile nt: 16 positions x 32 n x 8 k,
+//    packed on the host side in exactly the fragment order), unit u+1 written at the start of unit u and published by ONE
+//    barrier in the middle of unit u's MFMA stream;
+//  * K is the outer loop, so the channels of a finished stage are dead in the halo: the NEXT tile's halo is streamed in place,
+//    16 channels (64 B per pixel) at a time, through 3 float4 registers per thread -- no second halo buffer, no seam load;
+//  * epilogue: per output column parity b the waves write r_xi[b] = sum_nu M[xi][nu] A[nu][b] to LDS (over the idle weight
+//    ring), the cross-xi sum  Y[a][b] = sum_xi At[a][xi] r_xi[b]  is done by the reader, which stores 16 B per lane,
+//    256 B contiguous per pixel, with LeakyReLU / LeakyReLU' mask / residuals applied.
+// LDS: 340 x 256 B halo + 64 KB ring/exchange = 152,576 B, one block per CU, 2 waves per SIMD.
+#include <stdlib.h>
+
+#include "lfsr_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef LFSR_CONV_DIAG
+// diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
+#define STAMP(k) do { if (wave == 0) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int TR = 8, TC = 32;
+constexpr int HALO_PIX = (TR + 2) * (TC + 2);      // 340
+constexpr int HALO_FLOATS = HALO_PIX * 64;         // 21760
+constexpr int UNIT_FLOATS = 4096;                  // 16 positions x 2 halves x 32 n x 4 k
+constexpr int XCH_FLOATS = 8 * 32 * 64;            // exchange: 8 waves x 32 tiles x 64 channels (covers the 3-unit ring)
+constexpr int SMEM_BYTES = (HALO_FLOATS + XCH_FLOATS) * 4;   // 152576
+
+struct WinoArgs {
+  const float* X; int x_stride; int x_choff;
+  const float* Wu;   // [8 stages][2 nt][16 p][2 half][32 n][4]   (lfsr_pack_wino)
+  float* Y; int y_stride; int y_choff;
+  const float* R1; int r1_stride; int r1_choff;
+  const float* R2; int r2_stride; int r2_choff;
+  const float* Mk; int mk_stride; int mk_choff; float mk_slope;
+  int n_img, H, W, tiles_y, tiles_x, ntiles;
+  float slope;
+};
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {   // s = +-1: exact
+  return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
+}
+
+// LDS-only barrier (global stores/loads stay in flight); the sched_barriers pin the MFMA stream around it
+#define LDS_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// opaque copy: blocks loop-invariant hoisting / CSE of everything derived from x (address arithmetic is recomputed next to
+// its use instead of being kept -- and spilled -- across the 16 unrolled units)
+#define OPAQUE(x) asm volatile("" : "+v"(x))
+
+template <bool MASK>
+__global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sH = smem;                  // halo
+  float* sR = smem + HALO_FLOATS;    // weight ring (3 units) / epilogue exchange
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int mg = wave >> 2, xi = wave & 3;
+  const int ty = l31 >> 4, tx = l31 & 15;
+
+  // ---- patch addressing: t[jj] = d[ra][jj] + sg * d[rb][jj]  (row xi of Bt d) -------------------------------------
+  const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+  const int rb = xi == 3 ? 3 : (xi == 2 ? 1 : 2);
+  const float sg = xi == 1 ? 1.f : -1.f;
+  const int pixA = (4 * mg + 2 * ty + ra) * (TC + 2) + 2 * tx;   // halo pixel of patch column 0
+  const int pixB = (4 * mg + 2 * ty + rb) * (TC + 2) + 2 * tx;
+  // swizzle key of a pixel = (pix >> 1) & 15; columns 0,1 share one key, columns 2,3 the next
+  int kA0 = ((pixA >> 1) & 15) ^ half, kA1 = (((pixA >> 1) + 1) & 15) ^ half;
+  int kB0 = ((pixB >> 1) & 15) ^ half, kB1 = (((pixB >> 1) + 1) & 15) ^ half;
+  int offA = pixA * 64, offB = pixB * 64;                       // float offsets into the halo
+  int offBf = ((8 * xi + half) * 32 + l31) * 4;                 // B fragments: position p = 4 xi + nu -> + nu * 256 floats
+
+  // ---- halo streaming slots: slice g = logical chunks 4g..4g+3; slot i -> (pixel, chunk) = (idx >> 2, idx & 3) ------
+  int vtid = tid;   // laundered copy of the thread id for the per-slot arithmetic
+
+  auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
+    int txx = t % p.tiles_x; int q = t / p.tiles_x;
+    int tyy = q % p.tiles_y; img = q / p.tiles_y;
+    y0 = tyy * TR; x0 = txx * TC;
+  };
+  auto halo_load = [&](int g, int i, int img, int y0, int x0) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int px = (vtid + 512 * i) >> 2, cq = vtid & 3;
+    if (px < HALO_PIX) {
+      int r = px / (TC + 2), c = px - r * (TC + 2);
+      int yy = y0 + r - 1, xx = x0 + c - 1;
+      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+        v = *reinterpret_cast<const float4*>(p.X + ((long long)img * p.H * p.W + (long long)yy * p.W + xx) * p.x_stride + p.x_choff + (4 * g + cq) * 4);
+    }
+    return v;
+  };
+  auto halo_store = [&](int g, int i, float4 v) {
+    const int px = (vtid + 512 * i) >> 2, cq = vtid & 3;
+    if (px < HALO_PIX) *reinterpret_cast<float4*>(sH + px * 64 + (((4 * g + cq) ^ ((px >> 1) & 15)) << 2)) = v;
+  };
+  auto raw_read = [&](int j, float4* raw) {   // 2 rows x 4 columns of the patch, channels 8j + 4 half .. + 3
+    const int oA0 = ((2 * j) ^ kA0) << 2, oA1 = ((2 * j) ^ kA1) << 2;
+    const int oB0 = ((2 * j) ^ kB0) << 2, oB1 = ((2 * j) ^ kB1) << 2;
+    const float* hA = sH + offA;
+    const float* hB = sH + offB;
+    raw[0] = *reinterpret_cast<const float4*>(hA + oA0);
+    raw[1] = *reinterpret_cast<const float4*>(hA + 64 + oA0);
+    raw[2] = *reinterpret_cast<const float4*>(hA + 128 + oA1);
+    raw[3] = *reinterpret_cast<const float4*>(hA + 192 + oA1);
+    raw[4] = *reinterpret_cast<const float4*>(hB + oB0);
+    raw[5] = *reinterpret_cast<const float4*>(hB + 64 + oB0);
+    raw[6] = *reinterpret_cast<const float4*>(hB + 128 + oB1);
+    raw[7] = *reinterpret_cast<const float4*>(hB + 192 + oB1);
+  };
+
+  auto res_load = [&](int b, float4* res, int img, int y0, int x0) {
+    const float* src = MASK ? p.Mk : p.R1;
+    const int sst = MASK ? p.mk_stride : p.r1_stride, sco = MASK ? p.mk_choff : p.r1_choff;
+    if (src) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = vtid + 512 * i, c = o & 15, q = o >> 4;
+        const int R = q >> 4, col = 2 * (q & 15) + b;
+        res[i] = (y0 + R < p.H && x0 + col < p.W)
+                     ? *reinterpret_cast<const float4*>(src + ((long long)img * p.H * p.W + (long long)(y0 + R) * p.W + x0 + col) * sst + sco + c * 4)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  int img, y0, x0;
+  tile_origin(tile, img, y0, x0);
+
+  // ---- prologue: whole halo of the first tile, unit 0 into the ring, unit 1 in registers --------------------------
+  float4 hv[3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hv[i] = halo_load(g, i, img, y0, x0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) halo_store(g, i, hv[i]);
+  }
+  float4 wr0, wr1;   // staged weight unit (2 float4 per thread)
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.Wu);
+    float4 a = src[tid], b = src[tid + 512];
+    reinterpret_cast<float4*>(sR)[tid] = a;
+    reinterpret_cast<float4*>(sR)[tid + 512] = b;
+    wr0 = src[1024 + tid]; wr1 = src[1024 + tid + 512];
+  }
+  __syncthreads();
+  float4 raw[8];
+  raw_read(0, raw);
+  float4 B01[2], B23[2], nB01[2];
+  B01[0] = *reinterpret_cast<const float4*>(sR + offBf);
+  B01[1] = *reinterpret_cast<const float4*>(sR + offBf + 256);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][n][r] = 0.f;
+
+#ifdef LFSR_CONV_DIAG
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+  float* dbgbuf = const_cast<float*>(p.R2);
+  p.R2 = nullptr;
+#endif
+  while (true) {
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < p.ntiles;
+    int nimg = 0, ny0 = 0, nx0 = 0;
+    if (has_next) tile_origin(next, nimg, ny0, nx0);
+    float4 V[4];
+
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = u >> 1, nt = u & 1;
+      OPAQUE(kA0); OPAQUE(kA1); OPAQUE(kB0); OPAQUE(kB1); OPAQUE(offA); OPAQUE(offB); OPAQUE(offBf); OPAQUE(vtid);
+      const float* bBase = sR + offBf;
+      // S1: unit u+1 (in registers since unit u-1) -> ring; start fetching unit u+2 (unit 0 of the next tile at u = 14)
+      if (u < 15) {
+        float4* dst = reinterpret_cast<float4*>(sR + ((u + 1) % 3) * UNIT_FLOATS);
+        dst[vtid] = wr0; dst[vtid + 512] = wr1;
+      }
+      if (u < 15) {
+        const float4* src = reinterpret_cast<const float4*>(p.Wu) + ((u + 2) & 15) * 1024;
+        wr0 = src[vtid]; wr1 = src[vtid + 512];
+      }
+      // second half of this unit's B fragments (published by the previous unit's barrier)
+      {
+        const float* bu = bBase + (u % 3) * UNIT_FLOATS;
+        B23[0] = *reinterpret_cast<const float4*>(bu + 512);
+        B23[1] = *reinterpret_cast<const float4*>(bu + 768);
+      }
+      // S2: input transform of stage j, then request the patch of stage j+1
+      if (nt == 0) {
+        float4 t0 = f4fma(sg, raw[4], raw[0]), t1 = f4fma(sg, raw[5], raw[1]);
+        float4 t2 = f4fma(sg, raw[6], raw[2]), t3 = f4fma(sg, raw[7], raw[3]);
+        V[0] = f4sub(t0, t2); V[1] = f4add(t1, t2); V[2] = f4sub(t2, t1); V[3] = f4sub(t1, t3);
+        __builtin_amdgcn_sched_barrier(0);   // the old patch registers are dead before the new reads are issued
+        if (j < 7) raw_read(j + 1, raw);
+      }
+   // round-0 residual / LeakyReLU'-mask operand (the patch registers are free in stage 7)
+      // S3: positions nu = 0, 1
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, B01[0].x, acc[0][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, B01[1].x, acc[1][nt], 0, 0, 0);
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].y, B01[0].y, acc[0][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].y, B01[1].y, acc[1][nt], 0, 0, 0);
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].z, B01[0].z, acc[0][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].z, B01[1].z, acc[1][nt], 0, 0, 0);
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].w, B01[0].w, acc[0][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].w, B01[1].w, acc[1][nt], 0, 0, 0);
+      // S4: publishes unit u+1; every wave has finished unit u-1
+      LDS_BARRIER();
+      // S5: first half of the next unit's B fragments; in-place halo streaming at the first unit of stages 0, 2, 4, 6
+      if (u < 15) {
+        const float* bn = bBase + ((u + 1) % 3) * UNIT_FLOATS;
+        nB01[0] = *reinterpret_cast<const float4*>(bn);
+        nB01[1] = *reinterpret_cast<const float4*>(bn + 256);
+      }
+      if (has_next && (u & 3) == 0 && u > 0) {   // slice g-1 (stages 2g-2, 2g-1) is dead everywhere now
+#pragma unroll
+        for (int i = 0; i < 3; ++i) halo_store((u >> 2) - 1, i, hv[i]);
+      }
+      if (has_next && (u & 3) == 2) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hv[i] = halo_load(u >> 2, i, nimg, ny0, nx0);
+      }
+      // S6: positions nu = 2, 3
+      acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].x, B23[0].x, acc[2][nt], 0, 0, 0);
+      acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].x, B23[1].x, acc[3][nt], 0, 0, 0);
+      acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].y, B23[0].y, acc[2][nt], 0, 0, 0);
+      acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].y, B23[1].y, acc[3][nt], 0, 0, 0);
+      acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].z, B23[0].z, acc[2][nt], 0, 0, 0);
+      acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].z, B23[1].z, acc[3][nt], 0, 0, 0);
+      acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].w, B23[0].w, acc[2][nt], 0, 0, 0);
+      acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].w, B23[1].w, acc[3][nt], 0, 0, 0);
+      if (u < 15) { B01[0] = nB01[0]; B01[1] = nB01[1]; }
+    }
+
+    // ---- seam --------------------------------------------------------------------------------------------------
+    STAMP(0);        // 16 units
+    LDS_BARRIER();   // K loop finished everywhere: ring free, last halo slice dead
+    STAMP(1);        // seam barrier wait
+    OPAQUE(vtid); OPAQUE(offBf);
+    if (has_next) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) halo_store(3, i, hv[i]);
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      // r_xi[b] = sum_nu M[xi][nu] A[nu][b]:  b = 0: M0 + M1 + M2,  b = 1: M1 - M2 - M3   -> X[wave][tile][channel]
+      float4 res[4];
+      res_load(b, res, img, y0, x0);
+      float* xo = sR + wave * 2048 + (4 * half) * 64 + l31;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (r & 3) + 8 * (r >> 2);
+          float v = b == 0 ? (acc[0][nt][r] + acc[1][nt][r]) + acc[2][nt][r] : (acc[1][nt][r] - acc[2][nt][r]) - acc[3][nt][r];
+          xo[m * 64 + nt * 32] = v;
+        }
+      LDS_BARRIER();
+      STAMP(2 + 2 * b);   // exchange write + barrier
+      // Y[a][b] = sum_xi At[a][xi] r_xi[b]:  a = 0: r0 + r1 + r2,  a = 1: r1 - r2 - r3
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = vtid + 512 * i, c = o & 15, q = o >> 4;
+        const int R = q >> 4, txo = q & 15;
+        const int a = R & 1, m = ((R >> 1) & 1) * 16 + txo;
+        const float* xs = sR + ((R >> 2) * 4 + a) * 2048 + m * 64 + c * 4;
+        float4 e0 = *reinterpret_cast<const float4*>(xs);
+        float4 e1 = *reinterpret_cast<const float4*>(xs + 2048);
+        float4 e2 = *reinterpret_cast<const float4*>(xs + 4096);
+        float4 v = a == 0 ? f4add(f4add(e0, e1), e2) : f4sub(f4sub(e0, e1), e2);
+        const int col = 2 * txo + b;
+        if (y0 + R < p.H && x0 + col < p.W) {
+          const long long pix = (long long)img * p.H * p.W + (long long)(y0 + R) * p.W + x0 + col;
+          v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
+          v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
+          const float4 rs = res[i];
+          if (MASK) {
+            if (p.Mk) {
+              v.x *= rs.x > 0.f ? 1.f : p.mk_slope; v.y *= rs.y > 0.f ? 1.f : p.mk_slope;
+              v.z *= rs.z > 0.f ? 1.f : p.mk_slope; v.w *= rs.w > 0.f ? 1.f : p.mk_slope;
+            }
+            if (p.R1) {   // not on the hot path: late load
+              float4 r = *reinterpret_cast<const float4*>(p.R1 + pix * p.r1_stride + p.r1_choff + c * 4);
+              v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+          } else {
+            if (p.R1) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
+          }
+          if (p.R2) {
+            float4 r = *reinterpret_cast<const float4*>(p.R2 + pix * p.r2_stride + p.r2_choff + c * 4);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          *reinterpret_cast<float4*>(p.Y + pix * p.y_stride + p.y_choff + c * 4) = v;
+        }
+      }
+      if (b == 1 && !has_next) break;
+      LDS_BARRIER();   // exchange region free again
+      STAMP(3 + 2 * b);   // exchange read, combine, stores + barrier
+    }
+    if (!has_next) break;
+    // ---- restart the weight ring: unit 0 (in registers since unit 14) -> ring[0], fetch unit 1 ---------------------
+    {
+      float4* dst = reinterpret_cast<float4*>(sR);
+      dst[vtid] = wr0; dst[vtid + 512] = wr1;
+      const float4* src = reinterpret_cast<const float4*>(p.Wu) + 1024;
+      wr0 = src[vtid]; wr1 = src[vtid + 512];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[v][n][r] = 0.f;
+    LDS_BARRIER();
+    raw_read(0, raw);
+    B01[0] = *reinterpret_cast<const float4*>(sR + offBf);
+    B01[1] = *reinterpret_cast<const float4*>(sR + offBf + 256);
+    STAMP(6);   // ring restart + barrier
+    tile = next; img = nimg; y0 = ny0; x0 = nx0;
+  }
+#ifdef LFSR_CONV_DIAG
+  if (dbgbuf && tid == 0)
+    for (int k = 0; k < 8; ++k) dbgbuf[blockIdx.x * 8 + k] = (float)seg[k];
+#endif
+}
+
+// U = G g G^t per (n, k) from the direct pack [tap][n][k] -> [j = k/8][nt = n/32][p][half = (k/4)&1][n%32][k%4]
+__global__ __launch_bounds__(256) void k_pack_wino(const float* __restrict__ direct, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (n, k)
+  if (i >= 64 * 64) return;
+  const int n = i >> 6, k = i & 63;
+  double g[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)direct[(t * 64 + n) * 64 + k];
+  const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+  double tmp[4][3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tmp[a][c] = G[a][0] * g[0][c] + G[a][1] * g[1][c] + G[a][2] * g[2][c];
+  const int j = k >> 3, hf = (k >> 2) & 1, e = k & 3, nt = n >> 5, n32 = n & 31;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
+      const int pp = a * 4 + b;
+      out[(((((j * 2 + nt) * 16 + pp) * 2 + hf) * 32 + n32) << 2) + e] = (float)u;
+    }
+}
+
+}  // namespace
+
+int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st) {
+  if (!direct_packed || !out) return LFSR_E_ARG;
+  hipLaunchKernelGGL(k_pack_wino, dim3(16), dim3(256), 0, st, direct_packed, out);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+// w_wino: the Winograd-domain pack (lfsr_pack_wino); w_direct: the [9][64][64] pack, used by the channel-split tail launch.
+int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const float* w_wino, const float* w_direct, float* y, int y_stride, int y_choff,
+                             const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                             const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                             int n_img, int h, int w, float slope, hipStream_t st) {
+  static bool attr_set[64] = {};
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    attr_set[dev] = true;
+  }
+  const int ncu = cus[dev];
+  WinoArgs p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wu = w_wino;
+  p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
+  p.R1 = r1; p.r1_stride = r1_stride; p.r1_choff = r1_choff; p.R2 = r2; p.r2_stride = r2_stride; p.r2_choff = r2_choff;
+  p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
+  p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + TR - 1) / TR; p.tiles_x = (w + TC - 1) / TC; p.slope = slope;
+  const long long nblk = (long long)n_img * p.tiles_y * p.tiles_x;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;
+  // tiles beyond the last full round go to the direct kernel's channel-split tail launch (two blocks per tile)
+  int tail = (int)(nblk % ncu);
+  if (!w_direct || nblk < ncu || 2 * tail > ncu || getenv("LFSR_CONV_NOTAIL")) tail = 0;
+  const int body = (int)nblk - tail;
+  p.ntiles = body;
+  const unsigned grid = (unsigned)(body < ncu ? body : ncu);
+  if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((k_conv3x3_wino<false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  LFSR_CHECK_LAUNCH();
+  if (tail > 0)
+    return lfsr_conv3x3_halo_tail_launch(x, x_stride, x_choff, w_direct, y, y_stride, y_choff, r1, r1_stride, r1_choff, r2, r2_stride, r2_choff,
+                                         mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, body, tail, st);
+  return LFSR_OK;
+}

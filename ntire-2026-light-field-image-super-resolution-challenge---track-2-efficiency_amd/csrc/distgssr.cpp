@@ -49,6 +49,7 @@ struct lfsr_distgssr {
     sl.off = packed_floats;
     packed_floats += align64(sl.floats);
     if (kindT == 1 || kindT == 2) sl.floatsT = (size_t)T * ((Cc + 31) / 32 * 32) * O;
+    if (kindT == 1 && O == 64 && Cc == 64 && T == 9) sl.floatsT += LFSR_CONV3_WINO_FLOATS;   // lfsr_pack_weight_T appends the Winograd-domain copy
     if (kindT == 3 || kindT == 4) sl.floatsT = (size_t)(O / (kindT == 3 ? 16 : 32)) * ((Cc + 31) / 32 * 32) * (kindT == 3 ? 16 : 32);
     if (kindT) { sl.offT = packed_floats; packed_floats += align64(sl.floatsT); }
     sl.grad_off = n_params;

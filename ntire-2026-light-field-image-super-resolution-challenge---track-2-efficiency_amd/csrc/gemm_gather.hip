@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ f, int f
 
 extern "C" {
 
-size_t lfsr_packed_weight_floats(int O, int C, int taps) { return (size_t)taps * (size_t)npad32(O) * (size_t)C; }
+size_t lfsr_packed_weight_floats(int O, int C, int taps) {
+  size_t f = (size_t)taps * (size_t)npad32(O) * (size_t)C;
+  if (O == 64 && C == 64 && taps == 9) f += LFSR_CONV3_WINO_FLOATS;   // 3x3 64->64: the Winograd-domain copy follows the direct pack
+  return f;
+}
 
 int lfsr_pack_conv_weight(const float* w, float* packed, int O, int C, int taps, int perm, int ch, void* stream) {
   if (!w || !packed || O <= 0 || C <= 0 || taps <= 0 || (perm != 0 && perm != 1)) return LFSR_E_ARG;
@@ -176,6 +180,7 @@ int lfsr_pack_conv_weight(const float* w, float* packed, int O, int C, int taps,
   long long total = (long long)taps * npad32(O) * C;
   hipLaunchKernelGGL(k_pack_weight, dim3(lfsr_blocks(total, 256)), dim3(256), 0, lfsr_stream(stream), w, packed, O, C, taps, npad32(O), perm, ch);
   LFSR_CHECK_LAUNCH();
+  if (O == 64 && C == 64 && taps == 9 && perm == 0) return lfsr_pack_wino(packed, packed + LFSR_CONV3_DIRECT_FLOATS, lfsr_stream(stream));
   return LFSR_OK;
 }
 
@@ -186,10 +191,15 @@ int lfsr_conv3x3_fwd(const float* x, int x_stride, int x_choff, const float* w_p
   if (x_stride < x_choff + 64 || y_stride < y_choff + 64 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if ((long long)n_img * h * w >= (1LL << 31) / 4) return LFSR_E_ARG;
   {
-    // v2 halo-tile kernel needs 16-B aligned channel vectors on every operand; LFSR_CONV3X3=gather forces v1 (A/B runs)
+    // the tile kernels need 16-B aligned channel vectors on every operand; LFSR_CONV3X3 = halo | gather forces the direct
+    // 9-tap halo kernel / the v1 gather-GEMM (A/B runs)
     const char* sel = getenv("LFSR_CONV3X3");
     const bool force_v1 = sel && sel[0] == 'g';
+    const bool force_halo = sel && sel[0] == 'h';
     const bool al = !((y_stride | y_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!r2 || !((r2_stride | r2_choff) & 3));
+    if (al && !force_v1 && !force_halo)
+      return lfsr_conv3x3_wino_launch(x, x_stride, x_choff, w_packed + LFSR_CONV3_DIRECT_FLOATS, w_packed, y, y_stride, y_choff, r1, r1_stride, r1_choff,
+                                      r2, r2_stride, r2_choff, nullptr, 0, 0, 1.0f, n_img, h, w, slope, lfsr_stream(stream));
     if (al && !force_v1)
       return lfsr_conv3x3_halo_launch(x, x_stride, x_choff, w_packed, y, y_stride, y_choff, r1, r1_stride, r1_choff, r2, r2_stride, r2_choff,
                                       nullptr, 0, 0, 1.0f, n_img, h, w, slope, lfsr_stream(stream));

@@ -12,6 +12,19 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
                              int n_img, int h, int w, float slope, hipStream_t st);
+int lfsr_conv3x3_halo_tail_launch(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
+                                  const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                                  const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                                  int n_img, int h, int w, float slope, int tile_begin, int tile_count, hipStream_t st);
+// conv3x3_wino.hip: Winograd F(2x2,3x3) form of the same op.  A packed 3x3 64->64 weight is the direct pack [9][64][64]
+// (LFSR_CONV3_DIRECT_FLOATS) immediately followed by its Winograd-domain pack (LFSR_CONV3_WINO_FLOATS), see lfsr_pack_wino.
+#define LFSR_CONV3_DIRECT_FLOATS (9 * 64 * 64)
+#define LFSR_CONV3_WINO_FLOATS (16 * 64 * 64)
+int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st);
+int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const float* w_wino, const float* w_direct, float* y, int y_stride, int y_choff,
+                             const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                             const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                             int n_img, int h, int w, float slope, hipStream_t st);
 // epi_fused.hip  (t_h / t_v: optional (B*A*h*w, 32) buffers receiving the post-LeakyReLU stage-1 activations for backward)
 bool lfsr_epi_fused_ok(int A, int h, int w);
 int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,

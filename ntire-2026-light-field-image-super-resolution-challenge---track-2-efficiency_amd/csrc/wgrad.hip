@@ -345,5 +345,6 @@ int lfsr_pack_weight_T(const float* w, float* out, int O, int C, int T, int flip
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pack_weight_T, dim3(grid), dim3(256), 0, st, w, out, O, C, T, npad32(C), flip);
   LFSR_CHECK_LAUNCH();
+  if (O == 64 && C == 64 && T == 9 && flip == 1) return lfsr_pack_wino(out, out + LFSR_CONV3_DIRECT_FLOATS, st);   // dgrad runs the Winograd kernel too
   return LFSR_OK;
 }

@@ -17,8 +17,13 @@ for res in (None, r):
         capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=res, res2=dbg, out=y)   # R2 carries the debug buffer in the DIAG build
     torch.cuda.synchronize()
     d = dbg.reshape(256, 8).cpu().double()
-    names = ["9 taps", "seam barrier wait", "transpose+stores", "post-epilogue barrier", "halo LDS write+barrier", "-"]
-    tot = d[:, :5].sum(1).mean()
-    print(f"residual={res is not None}: mean cycles per block {tot:.0f} (tiles per block ~12.5)")
-    for k in range(5):
-        print(f"   {names[k]:26s} {d[:, k].mean():12.0f} cyc  {100 * d[:, k].mean() / tot:5.1f}%   per tile {d[:, k].mean() / 12.5:9.0f}")
+    if os.environ.get("LFSR_CONV3X3", "")[:1] == "h":
+        names = ["9 taps", "seam barrier wait", "transpose+stores", "post-epilogue barrier", "halo LDS write+barrier"]
+    else:   # Winograd kernel (default)
+        names = ["16 units (K loop)", "seam barrier wait", "round 0 write+barrier", "round 0 read/store+barrier", "round 1 write+barrier",
+                 "round 1 read/store+barrier", "ring restart+barrier"]
+    nk = len(names)
+    tot = d[:, :nk].sum(1).mean()
+    print(f"residual={res is not None}: mean cycles per block {tot:.0f} (tiles per block ~12)")
+    for k in range(nk):
+        print(f"   {names[k]:28s} {d[:, k].mean():12.0f} cyc  {100 * d[:, k].mean() / tot:5.1f}%   per tile {d[:, k].mean() / 12:9.0f}")
