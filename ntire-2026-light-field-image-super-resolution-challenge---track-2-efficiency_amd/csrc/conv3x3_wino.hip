@@ -29,6 +29,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef WINO_ABL
+#define WINO_ABL 0   // diagnostic timing builds: 1 = no K-loop barriers, 2 = no halo streaming, 4 = no weight staging, 8 = no patch reads
+#endif
 #ifdef LFSR_CONV_DIAG
 // diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
 #define STAMP(k) do { if (wave == 0) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
@@ -43,7 +46,7 @@ constexpr int HALO_PIX = (TR + 2) * (TC + 2);      // 340
 constexpr int HALO_FLOATS = HALO_PIX * 64;         // 21760
 constexpr int UNIT_FLOATS = 4096;                  // 16 positions x 2 halves x 32 n x 4 k
 constexpr int XCH_FLOATS = 8 * 32 * 64;            // exchange: 8 waves x 32 tiles x 64 channels (covers the 3-unit ring)
-constexpr int SMEM_BYTES = (HALO_FLOATS + XCH_FLOATS) * 4;   // 152576
+constexpr int SMEM_BYTES = (HALO_FLOATS + XCH_FLOATS + 256) * 4;   // 153600 (+1 KB landing zone for the unused halo slots)
 
 struct WinoArgs {
   const float* X; int x_stride; int x_choff;
@@ -68,6 +71,25 @@ __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {   // s = 
 // its use instead of being kept -- and spilled -- across the 16 unrolled units)
 #define OPAQUE(x) asm volatile("" : "+v"(x))
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = (int)0x80000000u;   // byte offset beyond every descriptor's range: loads return 0, stores are dropped
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, float4 f) {
+  f32x4 v;
+  v.x = f.x; v.y = f.y; v.z = f.z; v.w = f.w;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+
+// All global traffic goes through buffer descriptors with 32-bit byte offsets (the launcher checks every operand spans
+// < 2 GiB): zero padding and ragged edges are out-of-range offsets instead of branches, so the K loop has no control flow.
 template <bool MASK>
 __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -78,6 +100,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   const int half = lane >> 5, l31 = lane & 31;
   const int mg = wave >> 2, xi = wave & 3;
   const int ty = l31 >> 4, tx = l31 & 15;
+
+#ifdef LFSR_CONV_DIAG
+  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = clock64();
+  float* dbgbuf = const_cast<float*>(p.R2);
+  p.R2 = nullptr;
+#endif
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, OOB), rsW = make_rsrc(p.Wu, 16 * UNIT_FLOATS * 4), rsY = make_rsrc(p.Y, OOB);
+  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, (MASK ? p.Mk : p.R1) ? OOB : 0);   // prefetched epilogue operand
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(MASK ? p.R1 : p.R2, (MASK ? p.R1 : p.R2) ? OOB : 0);   // late epilogue operand
+  const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
+  const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
+  const bool has_e = (MASK ? p.Mk : p.R1) != nullptr, has_l = (MASK ? p.R1 : p.R2) != nullptr;
 
   // ---- patch addressing: t[jj] = d[ra][jj] + sg * d[rb][jj]  (row xi of Bt d) -------------------------------------
   const int ra = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
@@ -90,29 +125,29 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   int kB0 = ((pixB >> 1) & 15) ^ half, kB1 = (((pixB >> 1) + 1) & 15) ^ half;
   int offA = pixA * 64, offB = pixB * 64;                       // float offsets into the halo
   int offBf = ((8 * xi + half) * 32 + l31) * 4;                 // B fragments: position p = 4 xi + nu -> + nu * 256 floats
-
-  // ---- halo streaming slots: slice g = logical chunks 4g..4g+3; slot i -> (pixel, chunk) = (idx >> 2, idx & 3) ------
   int vtid = tid;   // laundered copy of the thread id for the per-slot arithmetic
 
+  // ---- halo streaming slots: slice g = logical chunks 4g..4g+3; slot i -> (pixel, chunk) = (idx >> 2, idx & 3), idx = tid + 512 i
   auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
     int txx = t % p.tiles_x; int q = t / p.tiles_x;
     int tyy = q % p.tiles_y; img = q / p.tiles_y;
     y0 = tyy * TR; x0 = txx * TC;
   };
-  auto halo_load = [&](int g, int i, int img, int y0, int x0) -> float4 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int px = (vtid + 512 * i) >> 2, cq = vtid & 3;
-    if (px < HALO_PIX) {
-      int r = px / (TC + 2), c = px - r * (TC + 2);
-      int yy = y0 + r - 1, xx = x0 + c - 1;
-      if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
-        v = *reinterpret_cast<const float4*>(p.X + ((long long)img * p.H * p.W + (long long)yy * p.W + xx) * p.x_stride + p.x_choff + (4 * g + cq) * 4);
+  auto halo_offsets = [&](int* hx, int img, int y0, int x0) {   // byte offsets of the 3 slots' (pixel, chunk 0..3), OOB outside the image
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int px = (vtid + 512 * i) >> 2, cq = vtid & 3;
+      const int r = px / (TC + 2), c = px - r * (TC + 2);
+      const int yy = y0 + r - 1, xx = x0 + c - 1;
+      const bool ok = px < HALO_PIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      hx[i] = ok ? (((img * p.H + yy) * p.W + xx) * p.x_stride + p.x_choff + cq * 4) * 4 : OOB;
     }
-    return v;
   };
   auto halo_store = [&](int g, int i, float4 v) {
     const int px = (vtid + 512 * i) >> 2, cq = vtid & 3;
-    if (px < HALO_PIX) *reinterpret_cast<float4*>(sH + px * 64 + (((4 * g + cq) ^ ((px >> 1) & 15)) << 2)) = v;
+    float* dst = sH + px * 64 + (((4 * g + cq) ^ ((px >> 1) & 15)) << 2);
+    if (i == 2) dst = px < HALO_PIX ? dst : smem + HALO_FLOATS + XCH_FLOATS + (vtid & 63) * 4;   // slots 340..383 do not exist
+    *reinterpret_cast<float4*>(dst) = v;
   };
   auto raw_read = [&](int j, float4* raw) {   // 2 rows x 4 columns of the patch, channels 8j + 4 half .. + 3
     const int oA0 = ((2 * j) ^ kA0) << 2, oA1 = ((2 * j) ^ kA1) << 2;
@@ -128,20 +163,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     raw[6] = *reinterpret_cast<const float4*>(hB + 128 + oB1);
     raw[7] = *reinterpret_cast<const float4*>(hB + 192 + oB1);
   };
-
-  auto res_load = [&](int b, float4* res, int img, int y0, int x0) {
-    const float* src = MASK ? p.Mk : p.R1;
-    const int sst = MASK ? p.mk_stride : p.r1_stride, sco = MASK ? p.mk_choff : p.r1_choff;
-    if (src) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int o = vtid + 512 * i, c = o & 15, q = o >> 4;
-        const int R = q >> 4, col = 2 * (q & 15) + b;
-        res[i] = (y0 + R < p.H && x0 + col < p.W)
-                     ? *reinterpret_cast<const float4*>(src + ((long long)img * p.H * p.W + (long long)(y0 + R) * p.W + x0 + col) * sst + sco + c * 4)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+  // epilogue output i of round b: (row R, column 2 txo + b, 16-B chunk c); pixel index or -1 outside the image
+  auto out_pixel = [&](int b, int i, int img, int y0, int x0) -> int {
+    const int q = (vtid + 512 * i) >> 4;
+    const int R = q >> 4, col = 2 * (q & 15) + b;
+    return (y0 + R < p.H && x0 + col < p.W) ? (img * p.H + y0 + R) * p.W + x0 + col : -1;
   };
 
   int tile = blockIdx.x;
@@ -150,20 +176,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
 
   // ---- prologue: whole halo of the first tile, unit 0 into the ring, unit 1 in registers --------------------------
   float4 hv[3];
+  int hx[3];
+  halo_offsets(hx, img, y0, x0);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) hv[i] = halo_load(g, i, img, y0, x0);
+    for (int i = 0; i < 3; ++i) hv[i] = bload(rsX, hx[i], g * 64);
 #pragma unroll
     for (int i = 0; i < 3; ++i) halo_store(g, i, hv[i]);
   }
   float4 wr0, wr1;   // staged weight unit (2 float4 per thread)
   {
-    const float4* src = reinterpret_cast<const float4*>(p.Wu);
-    float4 a = src[tid], b = src[tid + 512];
+    float4 a = bload(rsW, tid * 16, 0), b = bload(rsW, tid * 16, 8192);
     reinterpret_cast<float4*>(sR)[tid] = a;
     reinterpret_cast<float4*>(sR)[tid + 512] = b;
-    wr0 = src[1024 + tid]; wr1 = src[1024 + tid + 512];
+    wr0 = bload(rsW, tid * 16, UNIT_FLOATS * 4); wr1 = bload(rsW, tid * 16, UNIT_FLOATS * 4 + 8192);
   }
   __syncthreads();
   float4 raw[8];
@@ -180,18 +207,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[v][n][r] = 0.f;
 
-#ifdef LFSR_CONV_DIAG
-  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  long long tprev = clock64();
-  float* dbgbuf = const_cast<float*>(p.R2);
-  p.R2 = nullptr;
-#endif
   while (true) {
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < p.ntiles;
     int nimg = 0, ny0 = 0, nx0 = 0;
     if (has_next) tile_origin(next, nimg, ny0, nx0);
+    OPAQUE(vtid);
+    if (has_next) halo_offsets(hx, nimg, ny0, nx0);
+    else { hx[0] = OOB; hx[1] = OOB; hx[2] = OOB; }
     float4 V[4];
+    if (WINO_ABL & 8) { V[0] = raw[0]; V[1] = raw[1]; V[2] = raw[2]; V[3] = raw[3]; }
 
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
@@ -199,13 +224,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       OPAQUE(kA0); OPAQUE(kA1); OPAQUE(kB0); OPAQUE(kB1); OPAQUE(offA); OPAQUE(offB); OPAQUE(offBf); OPAQUE(vtid);
       const float* bBase = sR + offBf;
       // S1: unit u+1 (in registers since unit u-1) -> ring; start fetching unit u+2 (unit 0 of the next tile at u = 14)
-      if (u < 15) {
+      if (u < 15 && !(WINO_ABL & 4)) {
         float4* dst = reinterpret_cast<float4*>(sR + ((u + 1) % 3) * UNIT_FLOATS);
         dst[vtid] = wr0; dst[vtid + 512] = wr1;
-      }
-      if (u < 15) {
-        const float4* src = reinterpret_cast<const float4*>(p.Wu) + ((u + 2) & 15) * 1024;
-        wr0 = src[vtid]; wr1 = src[vtid + 512];
+        wr0 = bload(rsW, vtid * 16, ((u + 2) & 15) * UNIT_FLOATS * 4);
+        wr1 = bload(rsW, vtid * 16, ((u + 2) & 15) * UNIT_FLOATS * 4 + 8192);
       }
       // second half of this unit's B fragments (published by the previous unit's barrier)
       {
@@ -214,14 +237,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
         B23[1] = *reinterpret_cast<const float4*>(bu + 768);
       }
       // S2: input transform of stage j, then request the patch of stage j+1
-      if (nt == 0) {
+      if (nt == 0 && !(WINO_ABL & 8)) {
         float4 t0 = f4fma(sg, raw[4], raw[0]), t1 = f4fma(sg, raw[5], raw[1]);
         float4 t2 = f4fma(sg, raw[6], raw[2]), t3 = f4fma(sg, raw[7], raw[3]);
         V[0] = f4sub(t0, t2); V[1] = f4add(t1, t2); V[2] = f4sub(t2, t1); V[3] = f4sub(t1, t3);
         __builtin_amdgcn_sched_barrier(0);   // the old patch registers are dead before the new reads are issued
         if (j < 7) raw_read(j + 1, raw);
       }
-   // round-0 residual / LeakyReLU'-mask operand (the patch registers are free in stage 7)
       // S3: positions nu = 0, 1
       acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, B01[0].x, acc[0][nt], 0, 0, 0);
       acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, B01[1].x, acc[1][nt], 0, 0, 0);
@@ -232,20 +254,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].w, B01[0].w, acc[0][nt], 0, 0, 0);
       acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].w, B01[1].w, acc[1][nt], 0, 0, 0);
       // S4: publishes unit u+1; every wave has finished unit u-1
-      LDS_BARRIER();
-      // S5: first half of the next unit's B fragments; in-place halo streaming at the first unit of stages 0, 2, 4, 6
+      if (!(WINO_ABL & 1)) LDS_BARRIER();
+      // S5: first half of the next unit's B fragments; in-place halo streaming: slice g (stages 2g, 2g+1) is dead everywhere
+      // once the barrier of unit 4g+4 has passed -- store it there, load it two units earlier
       if (u < 15) {
         const float* bn = bBase + ((u + 1) % 3) * UNIT_FLOATS;
         nB01[0] = *reinterpret_cast<const float4*>(bn);
         nB01[1] = *reinterpret_cast<const float4*>(bn + 256);
       }
-      if (has_next && (u & 3) == 0 && u > 0) {   // slice g-1 (stages 2g-2, 2g-1) is dead everywhere now
+      if ((u & 3) == 0 && u > 0 && !(WINO_ABL & 2)) {   // (no next tile: hv holds zeros, the halo is dead -- harmless)
 #pragma unroll
         for (int i = 0; i < 3; ++i) halo_store((u >> 2) - 1, i, hv[i]);
       }
-      if (has_next && (u & 3) == 2) {
+      if ((u & 3) == 2 && !(WINO_ABL & 2)) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) hv[i] = halo_load(u >> 2, i, nimg, ny0, nx0);
+        for (int i = 0; i < 3; ++i) hv[i] = bload(rsX, hx[i], (u >> 2) * 64);
       }
       // S6: positions nu = 2, 3
       acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].x, B23[0].x, acc[2][nt], 0, 0, 0);
@@ -264,15 +287,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     LDS_BARRIER();   // K loop finished everywhere: ring free, last halo slice dead
     STAMP(1);        // seam barrier wait
     OPAQUE(vtid); OPAQUE(offBf);
-    if (has_next) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) halo_store(3, i, hv[i]);
-    }
+    for (int i = 0; i < 3; ++i) halo_store(3, i, hv[i]);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      // r_xi[b] = sum_nu M[xi][nu] A[nu][b]:  b = 0: M0 + M1 + M2,  b = 1: M1 - M2 - M3   -> X[wave][tile][channel]
+      // operands of this round's 4 outputs per thread: pixel, prefetched residual / mask, late residual
+      int opix[4];
       float4 res[4];
-      res_load(b, res, img, y0, x0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        opix[i] = out_pixel(b, i, img, y0, x0);
+        const int c4 = ((vtid + 512 * i) & 15) * 4;
+        if (has_e) res[i] = bload(rsE, opix[i] >= 0 ? (opix[i] * e_stride + e_choff + c4) * 4 : OOB, 0);
+      }
+      // r_xi[b] = sum_nu M[xi][nu] A[nu][b]:  b = 0: M0 + M1 + M2,  b = 1: M1 - M2 - M3   -> X[wave][tile][channel]
       float* xo = sR + wave * 2048 + (4 * half) * 64 + l31;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -295,30 +323,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
         float4 e1 = *reinterpret_cast<const float4*>(xs + 2048);
         float4 e2 = *reinterpret_cast<const float4*>(xs + 4096);
         float4 v = a == 0 ? f4add(f4add(e0, e1), e2) : f4sub(f4sub(e0, e1), e2);
-        const int col = 2 * txo + b;
-        if (y0 + R < p.H && x0 + col < p.W) {
-          const long long pix = (long long)img * p.H * p.W + (long long)(y0 + R) * p.W + x0 + col;
-          v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
-          v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
-          const float4 rs = res[i];
-          if (MASK) {
-            if (p.Mk) {
-              v.x *= rs.x > 0.f ? 1.f : p.mk_slope; v.y *= rs.y > 0.f ? 1.f : p.mk_slope;
-              v.z *= rs.z > 0.f ? 1.f : p.mk_slope; v.w *= rs.w > 0.f ? 1.f : p.mk_slope;
-            }
-            if (p.R1) {   // not on the hot path: late load
-              float4 r = *reinterpret_cast<const float4*>(p.R1 + pix * p.r1_stride + p.r1_choff + c * 4);
-              v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-            }
-          } else {
-            if (p.R1) { v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w; }
-          }
-          if (p.R2) {
-            float4 r = *reinterpret_cast<const float4*>(p.R2 + pix * p.r2_stride + p.r2_choff + c * 4);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-          }
-          *reinterpret_cast<float4*>(p.Y + pix * p.y_stride + p.y_choff + c * 4) = v;
+        v.x = v.x >= 0.f ? v.x : v.x * p.slope; v.y = v.y >= 0.f ? v.y : v.y * p.slope;
+        v.z = v.z >= 0.f ? v.z : v.z * p.slope; v.w = v.w >= 0.f ? v.w : v.w * p.slope;
+        if (MASK) {   // backward: LeakyReLU' from the saved activation, then the (rare) accumulate operand
+          v.x *= res[i].x > 0.f ? 1.f : p.mk_slope; v.y *= res[i].y > 0.f ? 1.f : p.mk_slope;
+          v.z *= res[i].z > 0.f ? 1.f : p.mk_slope; v.w *= res[i].w > 0.f ? 1.f : p.mk_slope;
+        } else if (has_e) {
+          v = f4add(v, res[i]);
         }
+        if (has_l) v = f4add(v, bload(rsL, opix[i] >= 0 ? (opix[i] * l_stride + l_choff + c * 4) * 4 : OOB, 0));   // rare: late load
+        bstore(rsY, opix[i] >= 0 ? (opix[i] * p.y_stride + p.y_choff + c * 4) * 4 : OOB, v);
       }
       if (b == 1 && !has_next) break;
       LDS_BARRIER();   // exchange region free again
@@ -329,8 +343,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     {
       float4* dst = reinterpret_cast<float4*>(sR);
       dst[vtid] = wr0; dst[vtid + 512] = wr1;
-      const float4* src = reinterpret_cast<const float4*>(p.Wu) + 1024;
-      wr0 = src[vtid]; wr1 = src[vtid + 512];
+      wr0 = bload(rsW, vtid * 16, UNIT_FLOATS * 4); wr1 = bload(rsW, vtid * 16, UNIT_FLOATS * 4 + 8192);
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v)
