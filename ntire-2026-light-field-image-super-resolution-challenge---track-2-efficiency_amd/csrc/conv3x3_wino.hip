@@ -30,7 +30,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef WINO_ABL
-#define WINO_ABL 0   // diagnostic timing builds: 1 = no K-loop barriers, 2 = no halo streaming, 4 = no weight staging, 8 = no patch reads
+#define WINO_ABL 0   // diagnostic timing builds: 1 = no K-loop barriers, 2 = no halo streaming, 4 = no weight staging, 8 = no patch reads, 16 = half of them
 #endif
 #ifdef LFSR_CONV_DIAG
 // diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   const int ty = l31 >> 4, tx = l31 & 15;
 
 #ifdef LFSR_CONV_DIAG
-  long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long seg[32] = {};
   long long tprev = clock64();
   float* dbgbuf = const_cast<float*>(p.R2);
   p.R2 = nullptr;
@@ -120,9 +120,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   const float sg = xi == 1 ? 1.f : -1.f;
   const int pixA = (4 * mg + 2 * ty + ra) * (TC + 2) + 2 * tx;   // halo pixel of patch column 0
   const int pixB = (4 * mg + 2 * ty + rb) * (TC + 2) + 2 * tx;
-  // swizzle key of a pixel = (pix >> 1) & 15; columns 0,1 share one key, columns 2,3 the next
-  int kA0 = ((pixA >> 1) & 15) ^ half, kA1 = (((pixA >> 1) + 1) & 15) ^ half;
-  int kB0 = ((pixB >> 1) & 15) ^ half, kB1 = (((pixB >> 1) + 1) & 15) ^ half;
+  // swizzle key of a halo pixel in column c: ((c >> 1) & 15) ^ ((c & 1) << 2) -- independent of the row, so the 16-lane
+  // groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32: tiles tx = 0..15 of either tile row) hit 16
+  // distinct 16-B slots; the parity bit keeps the 8-lane groups of the ds_write_b128 halo stores (2 pixels x 4 chunks) apart
+  int k0 = (tx & 15) ^ half, k1 = ((tx + 1) & 15) ^ half;   // patch columns 0 (1: ^4) and 2 (3: ^4), with the lane half folded in
   int offA = pixA * 64, offB = pixB * 64;                       // float offsets into the halo
   int offBf = ((8 * xi + half) * 32 + l31) * 4;                 // B fragments: position p = 4 xi + nu -> + nu * 256 floats
   int vtid = tid;   // laundered copy of the thread id for the per-slot arithmetic
@@ -133,35 +134,43 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     int tyy = q % p.tiles_y; img = q / p.tiles_y;
     y0 = tyy * TR; x0 = txx * TC;
   };
-  auto halo_offsets = [&](int* hx, int img, int y0, int x0) {   // byte offsets of the 3 slots' (pixel, chunk 0..3), OOB outside the image
+  // byte offsets of the 3 slots' (pixel, chunks 4g..4g+3 at + 64 g), OOB outside the image or when there is no such tile:
+  // scalar tile base + a per-thread part in 24-bit multiplies, no branches (this runs in the shadow of unit 0's MFMAs)
+  auto halo_offsets = [&](int* hx, bool valid, int img, int y0, int x0) {
+    const int base = (((img * p.H + y0 - 1) * p.W + x0 - 1) * p.x_stride + p.x_choff) * 4;   // wave-uniform
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int px = (vtid + 512 * i) >> 2, cq = vtid & 3;
-      const int r = px / (TC + 2), c = px - r * (TC + 2);
+      const int r = __mul24(px, 1928) >> 16;   // px / 34 for px < 384
+      const int c = px - r * (TC + 2);
       const int yy = y0 + r - 1, xx = x0 + c - 1;
-      const bool ok = px < HALO_PIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      hx[i] = ok ? (((img * p.H + yy) * p.W + xx) * p.x_stride + p.x_choff + cq * 4) * 4 : OOB;
+      const bool ok = valid && px < HALO_PIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      hx[i] = ok ? base + __mul24(__mul24(r, p.W) + c, p.x_stride * 4) + cq * 16 : OOB;
     }
   };
-  auto halo_store = [&](int g, int i, float4 v) {
+  // LDS float offset of halo slot i for slice 0; slice g flips the two 64-B bits: (4g + cq) ^ key = ((4g) ^ (key & 12)) | ((cq ^ key) & 3)
+  auto halo_slot_base = [&](int i) -> int {
     const int px = (vtid + 512 * i) >> 2, cq = vtid & 3;
-    float* dst = sH + px * 64 + (((4 * g + cq) ^ ((px >> 1) & 15)) << 2);
-    if (i == 2) dst = px < HALO_PIX ? dst : smem + HALO_FLOATS + XCH_FLOATS + (vtid & 63) * 4;   // slots 340..383 do not exist
-    *reinterpret_cast<float4*>(dst) = v;
+    const int col = px - (__mul24(px, 1928) >> 16) * (TC + 2);
+    const int key = ((col >> 1) & 15) ^ ((col & 1) << 2);
+    const int b = px * 64 + (((cq ^ key) & 3) << 2) + ((key & 12) << 2);
+    return (i < 2 || px < HALO_PIX) ? b : HALO_FLOATS + XCH_FLOATS + (vtid & 63) * 4;   // slots 340..383 do not exist: landing zone
   };
-  auto raw_read = [&](int j, float4* raw) {   // 2 rows x 4 columns of the patch, channels 8j + 4 half .. + 3
-    const int oA0 = ((2 * j) ^ kA0) << 2, oA1 = ((2 * j) ^ kA1) << 2;
-    const int oB0 = ((2 * j) ^ kB0) << 2, oB1 = ((2 * j) ^ kB1) << 2;
-    const float* hA = sH + offA;
-    const float* hB = sH + offB;
-    raw[0] = *reinterpret_cast<const float4*>(hA + oA0);
-    raw[1] = *reinterpret_cast<const float4*>(hA + 64 + oA0);
-    raw[2] = *reinterpret_cast<const float4*>(hA + 128 + oA1);
-    raw[3] = *reinterpret_cast<const float4*>(hA + 192 + oA1);
-    raw[4] = *reinterpret_cast<const float4*>(hB + oB0);
-    raw[5] = *reinterpret_cast<const float4*>(hB + 64 + oB0);
-    raw[6] = *reinterpret_cast<const float4*>(hB + 128 + oB1);
-    raw[7] = *reinterpret_cast<const float4*>(hB + 192 + oB1);
+  auto halo_store = [&](int g, int i, float4 v) { *reinterpret_cast<float4*>(smem + (halo_slot_base(i) ^ (16 * g))) = v; };
+  // 2 rows x 4 columns of the patch, channels 8j + 4 half .. + 3; the two rows are requested half a unit apart (a burst of
+  // 8 x 8 ds_read_b128 per CU holds up the B-fragment reads queued behind it -- LDS returns in order -- 4 do not)
+  auto raw_read = [&](int j, int row, float4* raw) {
+    const int o0 = ((2 * j) ^ k0) << 2, o1 = o0 ^ 16, o2 = ((2 * j) ^ k1) << 2, o3 = o2 ^ 16;
+    const float* hR = sH + (row == 0 ? offA : offB);
+    raw[4 * row + 0] = *reinterpret_cast<const float4*>(hR + o0);
+    raw[4 * row + 1] = *reinterpret_cast<const float4*>(hR + 64 + o1);
+    raw[4 * row + 2] = *reinterpret_cast<const float4*>(hR + 128 + o2);
+    raw[4 * row + 3] = *reinterpret_cast<const float4*>(hR + 192 + o3);
+  };
+  auto transform = [&](const float4* raw, float4* V) {   // V[nu] = row xi of (Bt d B)
+    float4 t0 = f4fma(sg, raw[4], raw[0]), t1 = f4fma(sg, raw[5], raw[1]);
+    float4 t2 = f4fma(sg, raw[6], raw[2]), t3 = f4fma(sg, raw[7], raw[3]);
+    V[0] = f4sub(t0, t2); V[1] = f4add(t1, t2); V[2] = f4sub(t2, t1); V[3] = f4sub(t1, t3);
   };
   // epilogue output i of round b: (row R, column 2 txo + b, 16-B chunk c); pixel index or -1 outside the image
   auto out_pixel = [&](int b, int i, int img, int y0, int x0) -> int {
@@ -173,11 +182,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   int tile = blockIdx.x;
   int img, y0, x0;
   tile_origin(tile, img, y0, x0);
+  // the persistent stride gridDim.x as (images, tile rows, tile columns): the next tile's origin by carries, no divisions
+  const int g_tx = (int)gridDim.x % p.tiles_x, g_q = (int)gridDim.x / p.tiles_x;
+  const int g_ty = g_q % p.tiles_y, g_img = g_q / p.tiles_y;
 
   // ---- prologue: whole halo of the first tile, unit 0 into the ring, unit 1 in registers --------------------------
   float4 hv[3];
   int hx[3];
-  halo_offsets(hx, img, y0, x0);
+  halo_offsets(hx, true, img, y0, x0);
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -186,6 +198,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     for (int i = 0; i < 3; ++i) halo_store(g, i, hv[i]);
   }
   float4 wr0, wr1;   // staged weight unit (2 float4 per thread)
+  float4 wx0, wx1;   // unit 1 of the next tile, fetched during unit 15 so that no load is queued behind the epilogue's stores
   {
     float4 a = bload(rsW, tid * 16, 0), b = bload(rsW, tid * 16, 8192);
     reinterpret_cast<float4*>(sR)[tid] = a;
@@ -194,7 +207,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   }
   __syncthreads();
   float4 raw[8];
-  raw_read(0, raw);
+  raw_read(0, 0, raw); raw_read(0, 1, raw);
   float4 B01[2], B23[2], nB01[2];
   B01[0] = *reinterpret_cast<const float4*>(sR + offBf);
   B01[1] = *reinterpret_cast<const float4*>(sR + offBf + 256);
@@ -211,17 +224,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < p.ntiles;
     int nimg = 0, ny0 = 0, nx0 = 0;
-    if (has_next) tile_origin(next, nimg, ny0, nx0);
-    OPAQUE(vtid);
-    if (has_next) halo_offsets(hx, nimg, ny0, nx0);
-    else { hx[0] = OOB; hx[1] = OOB; hx[2] = OOB; }
-    float4 V[4];
+    float4 V[4], nV[4];
     if (WINO_ABL & 8) { V[0] = raw[0]; V[1] = raw[1]; V[2] = raw[2]; V[3] = raw[3]; }
 
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int j = u >> 1, nt = u & 1;
-      OPAQUE(kA0); OPAQUE(kA1); OPAQUE(kB0); OPAQUE(kB1); OPAQUE(offA); OPAQUE(offB); OPAQUE(offBf); OPAQUE(vtid);
+      OPAQUE(k0); OPAQUE(k1); OPAQUE(offA); OPAQUE(offB); OPAQUE(offBf); OPAQUE(vtid);
       const float* bBase = sR + offBf;
       // S1: unit u+1 (in registers since unit u-1) -> ring; start fetching unit u+2 (unit 0 of the next tile at u = 14)
       if (u < 15 && !(WINO_ABL & 4)) {
@@ -230,20 +239,34 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
         wr0 = bload(rsW, vtid * 16, ((u + 2) & 15) * UNIT_FLOATS * 4);
         wr1 = bload(rsW, vtid * 16, ((u + 2) & 15) * UNIT_FLOATS * 4 + 8192);
       }
+      if (u == 0) {   // next tile's origin (by carries) and halo offsets, in the shadow of this unit's MFMAs
+        nx0 = x0 + g_tx * TC; ny0 = y0 + g_ty * TR; nimg = img + g_img;
+        if (nx0 >= p.tiles_x * TC) { nx0 -= p.tiles_x * TC; ny0 += TR; }
+        if (ny0 >= p.tiles_y * TR) { ny0 -= p.tiles_y * TR; nimg += 1; }
+        halo_offsets(hx, has_next, nimg, ny0, nx0);
+      }
+      // in-place halo streaming: slice g (stages 2g, 2g+1) of the NEXT tile is requested at unit 4g+1 -- right behind this
+      // unit's weight loads, so the first younger load that is waited for (vmcnt retires in order) is two units away --
+      // and stored at unit 4g+4, once the barrier there says every wave is done with this tile's slice g
+      if ((u & 3) == 1 && !(WINO_ABL & 2)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hv[i] = bload(rsX, hx[i], (u >> 2) * 64);
+      }
+      if (u == 15 && !(WINO_ABL & 4)) {
+        wx0 = bload(rsW, vtid * 16, UNIT_FLOATS * 4); wx1 = bload(rsW, vtid * 16, UNIT_FLOATS * 4 + 8192);
+      }
       // second half of this unit's B fragments (published by the previous unit's barrier)
       {
         const float* bu = bBase + (u % 3) * UNIT_FLOATS;
         B23[0] = *reinterpret_cast<const float4*>(bu + 512);
         B23[1] = *reinterpret_cast<const float4*>(bu + 768);
       }
-      // S2: input transform of stage j, then request the patch of stage j+1
+      // S2: the fragments V of stage j were formed during the previous (odd) unit, in the shadow of its MFMAs; request the
+      // patch of stage j+1 now, transform it during unit (j, 1)
       if (nt == 0 && !(WINO_ABL & 8)) {
-        float4 t0 = f4fma(sg, raw[4], raw[0]), t1 = f4fma(sg, raw[5], raw[1]);
-        float4 t2 = f4fma(sg, raw[6], raw[2]), t3 = f4fma(sg, raw[7], raw[3]);
-        V[0] = f4sub(t0, t2); V[1] = f4add(t1, t2); V[2] = f4sub(t2, t1); V[3] = f4sub(t1, t3);
-        __builtin_amdgcn_sched_barrier(0);   // the old patch registers are dead before the new reads are issued
-        if (j < 7) raw_read(j + 1, raw);
+        if (u == 0) transform(raw, V); else { V[0] = nV[0]; V[1] = nV[1]; V[2] = nV[2]; V[3] = nV[3]; }
       }
+      if (nt == 1 && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 1, raw);
       // S3: positions nu = 0, 1
       acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, B01[0].x, acc[0][nt], 0, 0, 0);
       acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, B01[1].x, acc[1][nt], 0, 0, 0);
@@ -253,22 +276,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].z, B01[1].z, acc[1][nt], 0, 0, 0);
       acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].w, B01[0].w, acc[0][nt], 0, 0, 0);
       acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].w, B01[1].w, acc[1][nt], 0, 0, 0);
+      // the region between two barriers holds 16 MFMAs (S6 of the previous unit, S3 of this one).  A 32x32x2 fp32 MFMA occupies
+      // the matrix pipe for 64 cycles but the SIMD's vector issue for only 8: up to ~6 VALU / LDS / VMEM instructions per wave
+      // hide in each gap, a longer run does not (the two waves of a SIMD run in lock-step, neither has an MFMA to offer
+      // meanwhile) -- so deal the region's other instructions out evenly, MFMA first after the barrier
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
       // S4: publishes unit u+1; every wave has finished unit u-1
       if (!(WINO_ABL & 1)) LDS_BARRIER();
-      // S5: first half of the next unit's B fragments; in-place halo streaming: slice g (stages 2g, 2g+1) is dead everywhere
-      // once the barrier of unit 4g+4 has passed -- store it there, load it two units earlier
+      // S5: the patch of stage j+1 (no LDS read is left in flight at the barrier's wait), first half of the next unit's B fragments; halo slice g-1 of the next tile goes in place at unit 4g
       if (u < 15) {
         const float* bn = bBase + ((u + 1) % 3) * UNIT_FLOATS;
         nB01[0] = *reinterpret_cast<const float4*>(bn);
         nB01[1] = *reinterpret_cast<const float4*>(bn + 256);
       }
+      __builtin_amdgcn_sched_barrier(0);   // LDS returns in order: the B fragments must not queue behind the 8 patch reads
+      if (nt == 0 && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 0, raw);
+      if (nt == 1 && j < 7 && !(WINO_ABL & 8)) transform(raw, nV);   // in the shadow of this unit's last 8 and the next unit's first 8 MFMAs
       if ((u & 3) == 0 && u > 0 && !(WINO_ABL & 2)) {   // (no next tile: hv holds zeros, the halo is dead -- harmless)
 #pragma unroll
         for (int i = 0; i < 3; ++i) halo_store((u >> 2) - 1, i, hv[i]);
-      }
-      if ((u & 3) == 2 && !(WINO_ABL & 2)) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) hv[i] = bload(rsX, hx[i], (u >> 2) * 64);
       }
       // S6: positions nu = 2, 3
       acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].x, B23[0].x, acc[2][nt], 0, 0, 0);
@@ -280,26 +312,28 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].w, B23[0].w, acc[2][nt], 0, 0, 0);
       acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].w, B23[1].w, acc[3][nt], 0, 0, 0);
       if (u < 15) { B01[0] = nB01[0]; B01[1] = nB01[1]; }
+      STAMP(8 + u);
     }
 
     // ---- seam --------------------------------------------------------------------------------------------------
-    STAMP(0);        // 16 units
     LDS_BARRIER();   // K loop finished everywhere: ring free, last halo slice dead
     STAMP(1);        // seam barrier wait
     OPAQUE(vtid); OPAQUE(offBf);
 #pragma unroll
     for (int i = 0; i < 3; ++i) halo_store(3, i, hv[i]);
+    // output pixels of both rounds; the prefetched operand (residual / LeakyReLU' mask) of a round is requested before any
+    // store of the previous round is queued (vmcnt retires in order: a load behind the stores would wait for them)
+    int opix0[4], opix1[4];
+    float4 res[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      opix0[i] = out_pixel(0, i, img, y0, x0);
+      opix1[i] = out_pixel(1, i, img, y0, x0);
+      if (has_e) res[i] = bload(rsE, opix0[i] >= 0 ? (opix0[i] * e_stride + e_choff + ((vtid + 512 * i) & 15) * 4) * 4 : OOB, 0);
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      // operands of this round's 4 outputs per thread: pixel, prefetched residual / mask, late residual
-      int opix[4];
-      float4 res[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        opix[i] = out_pixel(b, i, img, y0, x0);
-        const int c4 = ((vtid + 512 * i) & 15) * 4;
-        if (has_e) res[i] = bload(rsE, opix[i] >= 0 ? (opix[i] * e_stride + e_choff + c4) * 4 : OOB, 0);
-      }
+      int* opix = b == 0 ? opix0 : opix1;
       // r_xi[b] = sum_nu M[xi][nu] A[nu][b]:  b = 0: M0 + M1 + M2,  b = 1: M1 - M2 - M3   -> X[wave][tile][channel]
       float* xo = sR + wave * 2048 + (4 * half) * 64 + l31;
 #pragma unroll
@@ -313,6 +347,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       LDS_BARRIER();
       STAMP(2 + 2 * b);   // exchange write + barrier
       // Y[a][b] = sum_xi At[a][xi] r_xi[b]:  a = 0: r0 + r1 + r2,  a = 1: r1 - r2 - r3
+      float4 vo[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int o = vtid + 512 * i, c = o & 15, q = o >> 4;
@@ -332,8 +367,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
           v = f4add(v, res[i]);
         }
         if (has_l) v = f4add(v, bload(rsL, opix[i] >= 0 ? (opix[i] * l_stride + l_choff + c * 4) * 4 : OOB, 0));   // rare: late load
-        bstore(rsY, opix[i] >= 0 ? (opix[i] * p.y_stride + p.y_choff + c * 4) * 4 : OOB, v);
+        vo[i] = v;
       }
+      if (b == 0 && has_e) {   // round 1's operand, ahead of round 0's stores
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          res[i] = bload(rsE, opix1[i] >= 0 ? (opix1[i] * e_stride + e_choff + ((vtid + 512 * i) & 15) * 4) * 4 : OOB, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        bstore(rsY, opix[i] >= 0 ? (opix[i] * p.y_stride + p.y_choff + ((vtid + 512 * i) & 15) * 4) * 4 : OOB, vo[i]);
       if (b == 1 && !has_next) break;
       LDS_BARRIER();   // exchange region free again
       STAMP(3 + 2 * b);   // exchange read, combine, stores + barrier
@@ -343,7 +388,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     {
       float4* dst = reinterpret_cast<float4*>(sR);
       dst[vtid] = wr0; dst[vtid + 512] = wr1;
-      wr0 = bload(rsW, vtid * 16, UNIT_FLOATS * 4); wr1 = bload(rsW, vtid * 16, UNIT_FLOATS * 4 + 8192);
+      wr0 = wx0; wr1 = wx1;
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v)
@@ -352,7 +397,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[v][n][r] = 0.f;
     LDS_BARRIER();
-    raw_read(0, raw);
+    raw_read(0, 0, raw); raw_read(0, 1, raw);
     B01[0] = *reinterpret_cast<const float4*>(sR + offBf);
     B01[1] = *reinterpret_cast<const float4*>(sR + offBf + 256);
     STAMP(6);   // ring restart + barrier
@@ -360,7 +405,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   }
 #ifdef LFSR_CONV_DIAG
   if (dbgbuf && tid == 0)
-    for (int k = 0; k < 8; ++k) dbgbuf[blockIdx.x * 8 + k] = (float)seg[k];
+    for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
 #endif
 }
 

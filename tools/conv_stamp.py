@@ -11,18 +11,22 @@ n_img, h, w = 800, 32, 32
 M = n_img * h * w
 x = torch.randn(M, 64, device="cuda"); wt = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
 wp = capi.pack_conv_weight(wt); y = torch.empty(M, 64, device="cuda"); r = torch.randn(M, 64, device="cuda")
-dbg = torch.zeros(256 * 8 // 4, 4, device="cuda")   # 2-D so the wrapper takes a stride; stride is unused by the DIAG build
+dbg = torch.zeros(256 * 32 // 4, 4, device="cuda")   # 2-D so the wrapper takes a stride; stride is unused by the DIAG build
 for res in (None, r):
     for _ in range(5):
         capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=res, res2=dbg, out=y)   # R2 carries the debug buffer in the DIAG build
     torch.cuda.synchronize()
-    d = dbg.reshape(256, 8).cpu().double()
+    wino = os.environ.get("LFSR_CONV3X3", "")[:1] != "h"
+    d = dbg.reshape(256, 32).cpu().double() if wino else dbg.reshape(-1)[:2048].reshape(256, 8).cpu().double()
     if os.environ.get("LFSR_CONV3X3", "")[:1] == "h":
         names = ["9 taps", "seam barrier wait", "transpose+stores", "post-epilogue barrier", "halo LDS write+barrier"]
     else:   # Winograd kernel (default)
-        names = ["16 units (K loop)", "seam barrier wait", "round 0 write+barrier", "round 0 read/store+barrier", "round 1 write+barrier",
+        names = ["-", "seam barrier wait", "round 0 write+barrier", "round 0 read/store+barrier", "round 1 write+barrier",
                  "round 1 read/store+barrier", "ring restart+barrier"]
     nk = len(names)
+    if wino:
+        names = names + ["-"] + ["unit %2d" % u for u in range(16)]
+        nk = len(names)
     tot = d[:, :nk].sum(1).mean()
     print(f"residual={res is not None}: mean cycles per block {tot:.0f} (tiles per block ~12)")
     for k in range(nk):
