@@ -6,10 +6,12 @@ forward of the HIP path over one batch of 32 synthetic patches already resident 
 process per GPU (torchrun env), patches are independent so ranks share no data-path collective
 ("weak" scaling: 32 patches per GPU); RCCL is used only for the barrier and the max-over-ranks clock.
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel (the per-view 3x3 64->64 halo-tile conv,
-77 % of DistgSSR FLOPs, MFMA-bound in fp32): algorithmic FLOPs per launch = 2 * 576 * 64 * (B*25*32*32)
-divided by that kernel's average launch duration, measured with hipEvents recorded on the launch
-stream around every launch inside the timed region.  `cpu_baseline` = the numpy oracle (fp32 mode)
+One JSON line on rank 0.  `roofline` is for the dominant kernel (the per-view 3x3 64->64 conv, 77 % of
+DistgSSR FLOPs, MFMA-bound in fp32): algorithmic FLOPs per launch = 2 * 576 * 64 * (B*25*32*32) (SURVEY 8d:
+direct-conv 2 x MAC) divided by that op's average duration, measured with hipEvents recorded on the launch
+stream around every launch inside the timed region.  The op runs in Winograd F(2x2,3x3) form, which issues
+2.25x fewer MFMA flops than that count -- `achieved`/`peak` can therefore exceed 1; `mfma_util` is the physical
+matrix-pipe utilisation (flops actually issued / time / peak).  `cpu_baseline` = the numpy oracle (fp32 mode)
 timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
@@ -165,6 +167,14 @@ def main():
         M = BATCH * A * A * H * W
         conv_flop = 2.0 * 576 * 64 * M
         ach = conv_flop / (conv_avg_ms * 1e-3) / 1e12
+        direct = os.environ.get("LFSR_CONV3X3", "")[:1] in ("h", "g")
+        tiles = M // 256                      # 8 x 32-pixel tiles
+        tail = tiles % 256 if 2 * (tiles % 256) <= 256 else 0
+        # flops the MFMA pipe actually executes per op: Winograd tiles 16 x (2 x 256/4 x 64 x 64), direct tiles 9 x (2 x 256 x 64 x 64)
+        exec_flop = conv_flop if direct else (tiles - tail) * 16 * 2.0 * 64 * 64 * 64 + tail * 9 * 2.0 * 256 * 64 * 64
+        kname = ("k_conv3x3_halo (direct 9-tap halo-tile kernel + channel-split tail launch)" if direct else
+                 "k_conv3x3_wino (per-view 3x3 64->64 in Winograd F(2x2,3x3) form: persistent 8x32 tiles, 16 position-GEMMs on fp32 MFMA "
+                 "32x32x2, in-place halo streaming) + k_conv3x3_halo<NHALF> channel-split tail launch")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
         if os.path.exists(pmc):
@@ -182,8 +192,12 @@ def main():
                        "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "k_conv3x3_halo (per-view 3x3 64->64, persistent halo-tile kernel + channel-split tail launch, fp32 MFMA 32x32x2); duration = both launches of one conv op",
-                         "flop_per_launch": conv_flop, "avg_launch_ms": conv_avg_ms, "launches_timed": conv_n},
+                         "kernel": kname + "; duration = both launches of one conv op",
+                         "flop_per_launch": conv_flop, "executed_flop_per_launch": exec_flop,
+                         "mfma_util": exec_flop / (conv_avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                         "note": "achieved = algorithmic direct-conv flops (SURVEY 8d) / time; the Winograd form issues 2.25x fewer MFMA "
+                                 "flops, so frac may exceed 1 -- mfma_util is the matrix-pipe utilisation",
+                         "avg_launch_ms": conv_avg_ms, "launches_timed": conv_n},
             "model_tflops": FLOP_PER_PATCH * world * BATCH * args.steps / el / 1e12,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
         }
