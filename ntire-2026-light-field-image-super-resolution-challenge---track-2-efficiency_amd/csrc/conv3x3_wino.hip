@@ -198,33 +198,29 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     for (int i = 0; i < 3; ++i) halo_store(g, i, hv[i]);
   }
   float4 wr0, wr1;   // staged weight unit (2 float4 per thread)
-  float4 wx0, wx1;   // unit 1 of the next tile, fetched during unit 15 so that no load is queued behind the epilogue's stores
-  {
-    float4 a = bload(rsW, tid * 16, 0), b = bload(rsW, tid * 16, 8192);
-    reinterpret_cast<float4*>(sR)[tid] = a;
-    reinterpret_cast<float4*>(sR)[tid + 512] = b;
-    wr0 = bload(rsW, tid * 16, UNIT_FLOATS * 4); wr1 = bload(rsW, tid * 16, UNIT_FLOATS * 4 + 8192);
+  float4 wx0, wx1, wy0, wy1;   // units 1 and 2 of the next tile, fetched during unit 15: no load is queued right behind the epilogue's stores
+  {   // units 0, 1, 2 into the three ring slots
+    float4* dst = reinterpret_cast<float4*>(sR);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[tid + 512 * k] = bload(rsW, tid * 16, 8192 * k);
   }
   __syncthreads();
   float4 raw[8];
   raw_read(0, 0, raw); raw_read(0, 1, raw);
   float4 B01[2], B23[2], nB01[2];
+  float4 nV[4];   // fragments of the next stage (stage 0 of a tile: formed in the prologue / at the seam)
+  transform(raw, nV);
   B01[0] = *reinterpret_cast<const float4*>(sR + offBf);
   B01[1] = *reinterpret_cast<const float4*>(sR + offBf + 256);
 
   f32x16 acc[4][2];
-#pragma unroll
-  for (int v = 0; v < 4; ++v)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[v][n][r] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   while (true) {
     const int next = tile + (int)gridDim.x;
     const bool has_next = next < p.ntiles;
     int nimg = 0, ny0 = 0, nx0 = 0;
-    float4 V[4], nV[4];
+    float4 V[4];
     if (WINO_ABL & 8) { V[0] = raw[0]; V[1] = raw[1]; V[2] = raw[2]; V[3] = raw[3]; }
 
 #pragma unroll
@@ -232,12 +228,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       const int j = u >> 1, nt = u & 1;
       OPAQUE(k0); OPAQUE(k1); OPAQUE(offA); OPAQUE(offB); OPAQUE(offBf); OPAQUE(vtid);
       const float* bBase = sR + offBf;
-      // S1: unit u+1 (in registers since unit u-1) -> ring; start fetching unit u+2 (unit 0 of the next tile at u = 14)
-      if (u < 15 && !(WINO_ABL & 4)) {
+      // S1: unit u+1 (in registers since unit u-1) -> ring; start fetching unit u+2 (unit 0 of the next tile at u = 14).
+      // Units 0, 1, 2 are already in the ring when a tile starts (written at the seam from loads issued BEFORE the epilogue's
+      // stores): vmcnt retires in order, so the first load issued behind the store burst (unit 3, at u = 0) is not
+      // waited for until u = 2, by when the stores have drained
+      if (u >= 2 && u < 15 && !(WINO_ABL & 4)) {
         float4* dst = reinterpret_cast<float4*>(sR + ((u + 1) % 3) * UNIT_FLOATS);
         dst[vtid] = wr0; dst[vtid + 512] = wr1;
-        wr0 = bload(rsW, vtid * 16, ((u + 2) & 15) * UNIT_FLOATS * 4);
-        wr1 = bload(rsW, vtid * 16, ((u + 2) & 15) * UNIT_FLOATS * 4 + 8192);
+      }
+      if (u != 1 && u < 15 && !(WINO_ABL & 4)) {
+        const int un = u == 0 ? 3 : (u + 2) & 15;
+        wr0 = bload(rsW, vtid * 16, un * UNIT_FLOATS * 4);
+        wr1 = bload(rsW, vtid * 16, un * UNIT_FLOATS * 4 + 8192);
       }
       if (u == 0) {   // next tile's origin (by carries) and halo offsets, in the shadow of this unit's MFMAs
         nx0 = x0 + g_tx * TC; ny0 = y0 + g_ty * TR; nimg = img + g_img;
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       }
       if (u == 15 && !(WINO_ABL & 4)) {
         wx0 = bload(rsW, vtid * 16, UNIT_FLOATS * 4); wx1 = bload(rsW, vtid * 16, UNIT_FLOATS * 4 + 8192);
+        wy0 = bload(rsW, vtid * 16, 2 * UNIT_FLOATS * 4); wy1 = bload(rsW, vtid * 16, 2 * UNIT_FLOATS * 4 + 8192);
       }
       // second half of this unit's B fragments (published by the previous unit's barrier)
       {
@@ -264,12 +267,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       // S2: the fragments V of stage j were formed during the previous (odd) unit, in the shadow of its MFMAs; request the
       // patch of stage j+1 now, transform it during unit (j, 1)
       if (nt == 0 && !(WINO_ABL & 8)) {
-        if (u == 0) transform(raw, V); else { V[0] = nV[0]; V[1] = nV[1]; V[2] = nV[2]; V[3] = nV[3]; }
+        V[0] = nV[0]; V[1] = nV[1]; V[2] = nV[2]; V[3] = nV[3];
       }
       if (nt == 1 && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 1, raw);
       // S3: positions nu = 0, 1
-      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, B01[0].x, acc[0][nt], 0, 0, 0);
-      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, B01[1].x, acc[1][nt], 0, 0, 0);
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, B01[0].x, j == 0 ? zero16 : acc[0][nt], 0, 0, 0);   // stage 0: C = 0, no zeroing pass
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, B01[1].x, j == 0 ? zero16 : acc[1][nt], 0, 0, 0);
       acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].y, B01[0].y, acc[0][nt], 0, 0, 0);
       acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].y, B01[1].y, acc[1][nt], 0, 0, 0);
       acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].z, B01[0].z, acc[0][nt], 0, 0, 0);
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
         for (int i = 0; i < 3; ++i) halo_store((u >> 2) - 1, i, hv[i]);
       }
       // S6: positions nu = 2, 3
-      acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].x, B23[0].x, acc[2][nt], 0, 0, 0);
-      acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].x, B23[1].x, acc[3][nt], 0, 0, 0);
+      acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].x, B23[0].x, j == 0 ? zero16 : acc[2][nt], 0, 0, 0);
+      acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].x, B23[1].x, j == 0 ? zero16 : acc[3][nt], 0, 0, 0);
       acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].y, B23[0].y, acc[2][nt], 0, 0, 0);
       acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].y, B23[1].y, acc[3][nt], 0, 0, 0);
       acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].z, B23[0].z, acc[2][nt], 0, 0, 0);
@@ -384,20 +387,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       STAMP(3 + 2 * b);   // exchange read, combine, stores + barrier
     }
     if (!has_next) break;
-    // ---- restart the weight ring: unit 0 (in registers since unit 14) -> ring[0], fetch unit 1 ---------------------
+    // ---- restart the weight ring: units 0, 1, 2 (in registers since units 14 / 15) -> ring slots 0, 1, 2 -------------
+    raw_read(0, 0, raw); raw_read(0, 1, raw);   // the next tile's halo has been complete since round 0's barrier
     {
       float4* dst = reinterpret_cast<float4*>(sR);
       dst[vtid] = wr0; dst[vtid + 512] = wr1;
-      wr0 = wx0; wr1 = wx1;
+      dst[vtid + 1024] = wx0; dst[vtid + 1536] = wx1;
+      dst[vtid + 2048] = wy0; dst[vtid + 2560] = wy1;
     }
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[v][n][r] = 0.f;
+    transform(raw, nV);
     LDS_BARRIER();
-    raw_read(0, 0, raw); raw_read(0, 1, raw);
     B01[0] = *reinterpret_cast<const float4*>(sR + offBf);
     B01[1] = *reinterpret_cast<const float4*>(sR + offBf + 256);
     STAMP(6);   // ring restart + barrier
