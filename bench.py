@@ -169,12 +169,11 @@ def main():
         ach = conv_flop / (conv_avg_ms * 1e-3) / 1e12
         direct = os.environ.get("LFSR_CONV3X3", "")[:1] in ("h", "g")
         tiles = M // 256                      # 8 x 32-pixel tiles
-        tail = tiles % 256 if 2 * (tiles % 256) <= 256 else 0
-        # flops the MFMA pipe actually executes per op: Winograd tiles 16 x (2 x 256/4 x 64 x 64), direct tiles 9 x (2 x 256 x 64 x 64)
-        exec_flop = conv_flop if direct else (tiles - tail) * 16 * 2.0 * 64 * 64 * 64 + tail * 9 * 2.0 * 256 * 64 * 64
+        # flops the MFMA pipe actually executes per op: a Winograd tile is 16 position-GEMMs of 2 x 64 x 64 x 64 (a direct tile 9 x 2 x 256 x 64 x 64)
+        exec_flop = conv_flop if direct else tiles * 16 * 2.0 * 64 * 64 * 64
         kname = ("k_conv3x3_halo (direct 9-tap halo-tile kernel + channel-split tail launch)" if direct else
                  "k_conv3x3_wino (per-view 3x3 64->64 in Winograd F(2x2,3x3) form: persistent 8x32 tiles, 16 position-GEMMs on fp32 MFMA "
-                 "32x32x2, in-place halo streaming) + k_conv3x3_halo<NHALF> channel-split tail launch")
+                 "32x32x2, in-place halo streaming; body launch + channel-split tail launch of the same kernel)")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
         if os.path.exists(pmc):

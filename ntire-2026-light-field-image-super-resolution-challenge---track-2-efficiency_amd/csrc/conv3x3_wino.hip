@@ -56,6 +56,7 @@ struct WinoArgs {
   const float* R2; int r2_stride; int r2_choff;
   const float* Mk; int mk_stride; int mk_choff; float mk_slope;
   int n_img, H, W, tiles_y, tiles_x, ntiles;
+  int tile_begin;   // NHALF launch: first tile of its range
   float slope;
 };
 
@@ -90,8 +91,14 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, float
 
 // All global traffic goes through buffer descriptors with 32-bit byte offsets (the launcher checks every operand spans
 // < 2 GiB): zero padding and ragged edges are out-of-range offsets instead of branches, so the K loop has no control flow.
-template <bool MASK>
+// NHALF = true: tail launch.  When the tile count is not a multiple of the CU count the leftover tiles are given to TWO blocks
+// each, block (2t + nh) computing output channels [32 nh, 32 nh + 32) of tile t: one N-tile per wave, 8 units instead of 16
+// (half the MFMAs, ~0.55 of a tile time), one tile per block.
+template <bool MASK, bool NHALF>
 __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
+  constexpr int NU = NHALF ? 8 : 16;           // units per tile
+  constexpr int NOUT = NHALF ? 2 : 4;          // epilogue outputs (float4) per thread and round
+  const int nh = NHALF ? (int)(blockIdx.x & 1) : 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sH = smem;                  // halo
   float* sR = smem + HALO_FLOATS;    // weight ring (3 units) / epilogue exchange
@@ -174,12 +181,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   };
   // epilogue output i of round b: (row R, column 2 txo + b, 16-B chunk c); pixel index or -1 outside the image
   auto out_pixel = [&](int b, int i, int img, int y0, int x0) -> int {
-    const int q = (vtid + 512 * i) >> 4;
+    const int q = (vtid + 512 * i) >> (NHALF ? 3 : 4);
     const int R = q >> 4, col = 2 * (q & 15) + b;
     return (y0 + R < p.H && x0 + col < p.W) ? (img * p.H + y0 + R) * p.W + x0 + col : -1;
   };
 
-  int tile = blockIdx.x;
+  auto chunk_of = [&](int i) -> int { const int o = vtid + 512 * i; return NHALF ? (o & 7) + 8 * nh : (o & 15); };   // 16-B channel chunk of output i
+  int tile = NHALF ? p.tile_begin + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   int img, y0, x0;
   tile_origin(tile, img, y0, x0);
   // the persistent stride gridDim.x as (images, tile rows, tile columns): the next tile's origin by carries, no divisions
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   {   // units 0, 1, 2 into the three ring slots
     float4* dst = reinterpret_cast<float4*>(sR);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dst[tid + 512 * k] = bload(rsW, tid * 16, 8192 * k);
+    for (int k = 0; k < 6; ++k) dst[tid + 512 * k] = bload(rsW, tid * 16, NHALF ? ((k >> 1) * 2 + nh) * UNIT_FLOATS * 4 + (k & 1) * 8192 : 8192 * k);
   }
   __syncthreads();
   float4 raw[8];
@@ -218,30 +226,31 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
 
   while (true) {
     const int next = tile + (int)gridDim.x;
-    const bool has_next = next < p.ntiles;
+    const bool has_next = !NHALF && next < p.ntiles;
     int nimg = 0, ny0 = 0, nx0 = 0;
     float4 V[4];
     if (WINO_ABL & 8) { V[0] = raw[0]; V[1] = raw[1]; V[2] = raw[2]; V[3] = raw[3]; }
 
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int j = u >> 1, nt = u & 1;
+    for (int u = 0; u < NU; ++u) {
+      const int j = NHALF ? u : u >> 1, nt = NHALF ? 0 : u & 1;   // stage, accumulator column (NHALF: the wave's only N-tile)
+      const bool sfirst = NHALF || nt == 0, slast = NHALF || nt == 1;   // first / last unit of its stage
       OPAQUE(k0); OPAQUE(k1); OPAQUE(offA); OPAQUE(offB); OPAQUE(offBf); OPAQUE(vtid);
       const float* bBase = sR + offBf;
       // S1: unit u+1 (in registers since unit u-1) -> ring; start fetching unit u+2 (unit 0 of the next tile at u = 14).
       // Units 0, 1, 2 are already in the ring when a tile starts (written at the seam from loads issued BEFORE the epilogue's
       // stores): vmcnt retires in order, so the first load issued behind the store burst (unit 3, at u = 0) is not
       // waited for until u = 2, by when the stores have drained
-      if (u >= 2 && u < 15 && !(WINO_ABL & 4)) {
+      if (u >= 2 && u < NU - 1 && !(WINO_ABL & 4)) {
         float4* dst = reinterpret_cast<float4*>(sR + ((u + 1) % 3) * UNIT_FLOATS);
         dst[vtid] = wr0; dst[vtid + 512] = wr1;
       }
-      if (u != 1 && u < 15 && !(WINO_ABL & 4)) {
-        const int un = u == 0 ? 3 : (u + 2) & 15;
+      if (u != 1 && (NHALF ? u + 2 < NU || u == 0 : u < 15) && !(WINO_ABL & 4)) {
+        const int un = NHALF ? 2 * (u == 0 ? 3 : u + 2) + nh : (u == 0 ? 3 : (u + 2) & 15);
         wr0 = bload(rsW, vtid * 16, un * UNIT_FLOATS * 4);
         wr1 = bload(rsW, vtid * 16, un * UNIT_FLOATS * 4 + 8192);
       }
-      if (u == 0) {   // next tile's origin (by carries) and halo offsets, in the shadow of this unit's MFMAs
+      if (u == 0 && !NHALF) {   // next tile's origin (by carries) and halo offsets, in the shadow of this unit's MFMAs
         nx0 = x0 + g_tx * TC; ny0 = y0 + g_ty * TR; nimg = img + g_img;
         if (nx0 >= p.tiles_x * TC) { nx0 -= p.tiles_x * TC; ny0 += TR; }
         if (ny0 >= p.tiles_y * TR) { ny0 -= p.tiles_y * TR; nimg += 1; }
@@ -250,11 +259,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       // in-place halo streaming: slice g (stages 2g, 2g+1) of the NEXT tile is requested at unit 4g+1 -- right behind this
       // unit's weight loads, so the first younger load that is waited for (vmcnt retires in order) is two units away --
       // and stored at unit 4g+4, once the barrier there says every wave is done with this tile's slice g
-      if ((u & 3) == 1 && !(WINO_ABL & 2)) {
+      if (!NHALF && (u & 3) == 1 && !(WINO_ABL & 2)) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) hv[i] = bload(rsX, hx[i], (u >> 2) * 64);
       }
-      if (u == 15 && !(WINO_ABL & 4)) {
+      if (!NHALF && u == 15 && !(WINO_ABL & 4)) {
         wx0 = bload(rsW, vtid * 16, UNIT_FLOATS * 4); wx1 = bload(rsW, vtid * 16, UNIT_FLOATS * 4 + 8192);
         wy0 = bload(rsW, vtid * 16, 2 * UNIT_FLOATS * 4); wy1 = bload(rsW, vtid * 16, 2 * UNIT_FLOATS * 4 + 8192);
       }
@@ -266,10 +275,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       }
       // S2: the fragments V of stage j were formed during the previous (odd) unit, in the shadow of its MFMAs; request the
       // patch of stage j+1 now, transform it during unit (j, 1)
-      if (nt == 0 && !(WINO_ABL & 8)) {
+      if (sfirst && !(WINO_ABL & 8)) {
+        if (NHALF && u > 0) transform(raw, nV);   // (tail launch: not pipelined)
         V[0] = nV[0]; V[1] = nV[1]; V[2] = nV[2]; V[3] = nV[3];
       }
-      if (nt == 1 && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 1, raw);
+      if (!NHALF && slast && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 1, raw);
       // S3: positions nu = 0, 1
       acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0].x, B01[0].x, j == 0 ? zero16 : acc[0][nt], 0, 0, 0);   // stage 0: C = 0, no zeroing pass
       acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[1].x, B01[1].x, j == 0 ? zero16 : acc[1][nt], 0, 0, 0);
@@ -293,15 +303,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       // S4: publishes unit u+1; every wave has finished unit u-1
       if (!(WINO_ABL & 1)) LDS_BARRIER();
       // S5: the patch of stage j+1 (no LDS read is left in flight at the barrier's wait), first half of the next unit's B fragments; halo slice g-1 of the next tile goes in place at unit 4g
-      if (u < 15) {
+      if (u < NU - 1) {
         const float* bn = bBase + ((u + 1) % 3) * UNIT_FLOATS;
         nB01[0] = *reinterpret_cast<const float4*>(bn);
         nB01[1] = *reinterpret_cast<const float4*>(bn + 256);
       }
       __builtin_amdgcn_sched_barrier(0);   // LDS returns in order: the B fragments must not queue behind the 8 patch reads
-      if (nt == 0 && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 0, raw);
-      if (nt == 1 && j < 7 && !(WINO_ABL & 8)) transform(raw, nV);   // in the shadow of this unit's last 8 and the next unit's first 8 MFMAs
-      if ((u & 3) == 0 && u > 0 && !(WINO_ABL & 2)) {   // (no next tile: hv holds zeros, the halo is dead -- harmless)
+      if (sfirst && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 0, raw);
+      if (NHALF && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 1, raw);
+      if (!NHALF && slast && j < 7 && !(WINO_ABL & 8)) transform(raw, nV);   // in the shadow of this unit's last 8 and the next unit's first 8 MFMAs
+      if (!NHALF && (u & 3) == 0 && u > 0 && !(WINO_ABL & 2)) {   // (no next tile: hv holds zeros, the halo is dead -- harmless)
 #pragma unroll
         for (int i = 0; i < 3; ++i) halo_store((u >> 2) - 1, i, hv[i]);
       }
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].z, B23[1].z, acc[3][nt], 0, 0, 0);
       acc[2][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[2].w, B23[0].w, acc[2][nt], 0, 0, 0);
       acc[3][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[3].w, B23[1].w, acc[3][nt], 0, 0, 0);
-      if (u < 15) { B01[0] = nB01[0]; B01[1] = nB01[1]; }
+      if (u < NU - 1) { B01[0] = nB01[0]; B01[1] = nB01[1]; }
       STAMP(8 + u);
     }
 
@@ -322,17 +333,19 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     LDS_BARRIER();   // K loop finished everywhere: ring free, last halo slice dead
     STAMP(1);        // seam barrier wait
     OPAQUE(vtid); OPAQUE(offBf);
+    if (!NHALF) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) halo_store(3, i, hv[i]);
+      for (int i = 0; i < 3; ++i) halo_store(3, i, hv[i]);
+    }
     // output pixels of both rounds; the prefetched operand (residual / LeakyReLU' mask) of a round is requested before any
     // store of the previous round is queued (vmcnt retires in order: a load behind the stores would wait for them)
-    int opix0[4], opix1[4];
-    float4 res[4];
+    int opix0[NOUT], opix1[NOUT];
+    float4 res[NOUT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NOUT; ++i) {
       opix0[i] = out_pixel(0, i, img, y0, x0);
       opix1[i] = out_pixel(1, i, img, y0, x0);
-      if (has_e) res[i] = bload(rsE, opix0[i] >= 0 ? (opix0[i] * e_stride + e_choff + ((vtid + 512 * i) & 15) * 4) * 4 : OOB, 0);
+      if (has_e) res[i] = bload(rsE, opix0[i] >= 0 ? (opix0[i] * e_stride + e_choff + chunk_of(i) * 4) * 4 : OOB, 0);
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -340,20 +353,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       // r_xi[b] = sum_nu M[xi][nu] A[nu][b]:  b = 0: M0 + M1 + M2,  b = 1: M1 - M2 - M3   -> X[wave][tile][channel]
       float* xo = sR + wave * 2048 + (4 * half) * 64 + l31;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < (NHALF ? 1 : 2); ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = (r & 3) + 8 * (r >> 2);
           float v = b == 0 ? (acc[0][nt][r] + acc[1][nt][r]) + acc[2][nt][r] : (acc[1][nt][r] - acc[2][nt][r]) - acc[3][nt][r];
-          xo[m * 64 + nt * 32] = v;
+          xo[m * 64 + (NHALF ? nh : nt) * 32] = v;
         }
       LDS_BARRIER();
       STAMP(2 + 2 * b);   // exchange write + barrier
       // Y[a][b] = sum_xi At[a][xi] r_xi[b]:  a = 0: r0 + r1 + r2,  a = 1: r1 - r2 - r3
-      float4 vo[4];
+      float4 vo[NOUT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int o = vtid + 512 * i, c = o & 15, q = o >> 4;
+      for (int i = 0; i < NOUT; ++i) {
+        const int c = chunk_of(i), q = (vtid + 512 * i) >> (NHALF ? 3 : 4);
         const int R = q >> 4, txo = q & 15;
         const int a = R & 1, m = ((R >> 1) & 1) * 16 + txo;
         const float* xs = sR + ((R >> 2) * 4 + a) * 2048 + m * 64 + c * 4;
@@ -375,13 +388,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
       if (b == 0 && has_e) {   // round 1's operand, ahead of round 0's stores
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          res[i] = bload(rsE, opix1[i] >= 0 ? (opix1[i] * e_stride + e_choff + ((vtid + 512 * i) & 15) * 4) * 4 : OOB, 0);
+        for (int i = 0; i < NOUT; ++i)
+          res[i] = bload(rsE, opix1[i] >= 0 ? (opix1[i] * e_stride + e_choff + chunk_of(i) * 4) * 4 : OOB, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        bstore(rsY, opix[i] >= 0 ? (opix[i] * p.y_stride + p.y_choff + ((vtid + 512 * i) & 15) * 4) * 4 : OOB, vo[i]);
+      for (int i = 0; i < NOUT; ++i)
+        bstore(rsY, opix[i] >= 0 ? (opix[i] * p.y_stride + p.y_choff + chunk_of(i) * 4) * 4 : OOB, vo[i]);
       if (b == 1 && !has_next) break;
       LDS_BARRIER();   // exchange region free again
       STAMP(3 + 2 * b);   // exchange read, combine, stores + barrier
@@ -452,8 +465,10 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     int v = 0;
     cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
@@ -468,17 +483,38 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
   p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + TR - 1) / TR; p.tiles_x = (w + TC - 1) / TC; p.slope = slope;
   const long long nblk = (long long)n_img * p.tiles_y * p.tiles_x;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;
-  // tiles beyond the last full round go to the direct kernel's channel-split tail launch (two blocks per tile)
+  // every operand is addressed through a buffer descriptor with 32-bit byte offsets: spans of 2 GiB and more go to the direct kernel
+  {
+    int ms = x_stride > y_stride ? x_stride : y_stride;
+    if (r1 && r1_stride > ms) ms = r1_stride;
+    if (r2 && r2_stride > ms) ms = r2_stride;
+    if (mk && mk_stride > ms) ms = mk_stride;
+    if ((long long)n_img * h * w * ms * 4 >= (1LL << 31) || (long long)h * w >= (1 << 24)) {
+      if (!w_direct) return LFSR_E_ARG;
+      return lfsr_conv3x3_halo_launch(x, x_stride, x_choff, w_direct, y, y_stride, y_choff, r1, r1_stride, r1_choff, r2, r2_stride, r2_choff,
+                                      mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);
+    }
+  }
+  // tiles beyond the last full round (L = ntiles % CUs) go to a channel-split tail launch, two blocks per tile, when that halves
+  // the tail (2L <= CUs); LFSR_CONV_TAIL=halo runs the tail on the direct 9-tap kernel instead (A/B)
   int tail = (int)(nblk % ncu);
-  if (!w_direct || nblk < ncu || 2 * tail > ncu || getenv("LFSR_CONV_NOTAIL")) tail = 0;
+  if (nblk < ncu || 2 * tail > ncu || getenv("LFSR_CONV_NOTAIL")) tail = 0;
+  const char* tsel = getenv("LFSR_CONV_TAIL");
+  const bool tail_direct = tsel && tsel[0] == 'h' && w_direct;
   const int body = (int)nblk - tail;
   p.ntiles = body;
   const unsigned grid = (unsigned)(body < ncu ? body : ncu);
-  if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  else hipLaunchKernelGGL((k_conv3x3_wino<false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((k_conv3x3_wino<false, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
   LFSR_CHECK_LAUNCH();
-  if (tail > 0)
+  if (tail > 0 && tail_direct)
     return lfsr_conv3x3_halo_tail_launch(x, x_stride, x_choff, w_direct, y, y_stride, y_choff, r1, r1_stride, r1_choff, r2, r2_stride, r2_choff,
                                          mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, body, tail, st);
+  if (tail > 0) {
+    p.tile_begin = body; p.ntiles = body + tail;
+    if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true, true>), dim3(2 * tail), dim3(512), SMEM_BYTES, st, p);
+    else hipLaunchKernelGGL((k_conv3x3_wino<false, true>), dim3(2 * tail), dim3(512), SMEM_BYTES, st, p);
+    LFSR_CHECK_LAUNCH();
+  }
   return LFSR_OK;
 }

@@ -54,6 +54,26 @@ def test_conv3x3(B, A, h, w):
     assert np.abs(from_vcl(y2, B, 64, A, h, w) - ref2).max() < ATOL
 
 
+def test_conv3x3_tail_and_fallback_kernels(monkeypatch):
+    """320 tiles = one full round of 256 CUs + 64 leftover tiles -> the channel-split tail launch (two blocks per tile);
+    the direct 9-tap kernel (LFSR_CONV3X3=halo), its tail form (LFSR_CONV_TAIL=halo) and the v1 gather-GEMM must agree too"""
+    B, A, h, w = 5, 4, 32, 32
+    x = rnd((B, 64, A * h, A * w), 11)
+    wt = rnd((64, 64, 3, 3), 12, 0.05)
+    r1 = rnd((B, 64, A * h, A * w), 13)
+    ref = O.leaky_relu(O.conv2d(x.astype(np.float64), wt.astype(np.float64), dilation=(A, A), padding=(A, A)), 0.1) + r1
+    wp = capi.pack_conv_weight(dev(wt))
+    xv, rv = to_vcl(x, A), to_vcl(r1, A)
+    for env in ({}, {"LFSR_CONV_TAIL": "halo"}, {"LFSR_CONV_NOTAIL": "1"}, {"LFSR_CONV3X3": "halo"}, {"LFSR_CONV3X3": "gather"}):
+        for k in ("LFSR_CONV_TAIL", "LFSR_CONV_NOTAIL", "LFSR_CONV3X3"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        y = capi.conv3x3(xv, wp, B * A * A, h, w, slope=0.1, res1=rv)
+        torch.cuda.synchronize()
+        assert np.abs(from_vcl(y, B, 64, A, h, w) - ref).max() < ATOL, env
+
+
 @pytest.mark.parametrize("B,A,h,w", GEOMS)
 def test_angconv(B, A, h, w):
     x = rnd((B, 64, A * h, A * w), 4)
