@@ -553,3 +553,40 @@ def view_psnr_ssim(label, out, A):
                 S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
                 ss[b, u, v] = S[5:-5, 5:-5].mean()
     return ps, ss
+
+# ---- Winograd F(2x2, 3x3) restatement (checks the packed layout and the algebra of csrc/conv3x3_wino.hip) --------------------
+# Lavin & Gray's minimal filtering form of the per-view 3x3 correlation of model/SR/DistgSSR.py:22,47,64,79-83,101:
+#   Y = At [ sum_c (G g Gt) . (Bt d B) ] A   per 2x2 output tile, d = its 4x4 input patch (zero padded)
+WINO_G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+WINO_BT = np.array([[1.0, 0.0, -1.0, 0.0], [0.0, 1.0, 1.0, 0.0], [0.0, -1.0, 1.0, 0.0], [0.0, 1.0, 0.0, -1.0]])
+WINO_AT = np.array([[1.0, 1.0, 1.0, 0.0], [0.0, 1.0, -1.0, -1.0]])
+
+
+def winograd_weights(w):
+    """(O, C, 3, 3) -> U[4, 4, O, C] = G g Gt per (o, c), in the dtype of w"""
+    return np.einsum("ai,ocij,bj->aboc", WINO_G.astype(w.dtype), w, WINO_G.astype(w.dtype))
+
+
+def winograd_pack(w):
+    """the device layout of lfsr_pack_conv_weight's Winograd part for a (64, 64, 3, 3) weight:
+    [j = k/8][nt = n/32][p = 4 xi + nu][half = (k/4)&1][n%32][k%4], flattened (fp64 compute, one rounding to fp32)"""
+    U = winograd_weights(w.astype(np.float64)).reshape(16, 64, 64)          # [p][n][k]
+    U = U.reshape(16, 2, 32, 8, 2, 4)                                       # p, nt, n32, j, half, e
+    return np.ascontiguousarray(U.transpose(3, 1, 0, 4, 2, 5)).astype(np.float32).reshape(-1)
+
+
+def conv3x3_winograd(x, w):
+    """per-image 3x3 correlation, zero pad 1, via F(2x2,3x3): x (N, C, H, W) with even H, W; w (O, C, 3, 3)"""
+    N, C, H, W = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    U = winograd_weights(w)
+    y = np.zeros((N, w.shape[0], H, W), dtype=x.dtype)
+    BT, AT = WINO_BT.astype(x.dtype), WINO_AT.astype(x.dtype)
+    for ty in range(H // 2):
+        for tx in range(W // 2):
+            d = xp[:, :, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]
+            V = np.einsum("ai,ncij,bj->abnc", BT, d, BT)
+            M = np.einsum("aboc,abnc->abno", U, V)
+            y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ia,abno,jb->noij", AT, M, AT)
+    return y

@@ -54,6 +54,17 @@ def test_conv3x3(B, A, h, w):
     assert np.abs(from_vcl(y2, B, 64, A, h, w) - ref2).max() < ATOL
 
 
+def test_packed_conv_weight_carries_winograd_copy():
+    """lfsr_pack_conv_weight(64,64,3,3) = direct [9][64][64] pack followed by U = G g Gt in the fragment order of the kernel"""
+    wt = rnd((64, 64, 3, 3), 21, 0.05)
+    wp = capi.pack_conv_weight(dev(wt)).cpu().numpy()
+    assert wp.size == 9 * 64 * 64 + 16 * 64 * 64
+    direct = wt.reshape(64, 64, 9).transpose(2, 0, 1).reshape(-1)           # [tap][n][k]
+    assert np.array_equal(wp[:9 * 64 * 64], direct)
+    ref = O.winograd_pack(wt)
+    assert np.abs(wp[9 * 64 * 64:] - ref).max() <= 1e-9 and np.mean(wp[9 * 64 * 64:] == ref) > 0.999   # fp64 compute, one rounding
+
+
 def test_conv3x3_tail_and_fallback_kernels(monkeypatch):
     """320 tiles = one full round of 256 CUs + 64 leftover tiles -> the channel-split tail launch (two blocks per tile);
     the direct 9-tap kernel (LFSR_CONV3X3=halo), its tail form (LFSR_CONV_TAIL=halo) and the v1 gather-GEMM must agree too"""

@@ -146,3 +146,21 @@ def test_internet_small(tag):
     g = npz[tag + "_out"]
     assert y.shape == g.shape
     assert np.abs(y - g).max() < 5e-5 * max(1.0, np.abs(g).max())
+
+
+def test_winograd_restatement_equals_direct_conv():
+    """the F(2x2,3x3) algebra the HIP conv kernel implements (oracle.conv3x3_winograd) is the same correlation as conv2d"""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 8, 6, 8))
+    w = rng.standard_normal((4, 8, 3, 3))
+    ref = O.conv2d(x, w, padding=(1, 1))
+    assert np.abs(O.conv3x3_winograd(x, w) - ref).max() < 1e-12
+    # fp32 round-off of the Winograd form stays at fp32 epsilon scale on unit-variance data
+    y32 = O.conv3x3_winograd(x.astype(np.float32), w.astype(np.float32))
+    assert np.abs(y32 - ref).max() < 5e-5
+    # packed layout: entry (j, nt, p, half, n32, e) holds U[p][n = 32 nt + n32][k = 8 j + 4 half + e]
+    w64 = rng.standard_normal((64, 64, 3, 3)).astype(np.float32)
+    pk = O.winograd_pack(w64).reshape(8, 2, 16, 2, 32, 4)
+    U = O.winograd_weights(w64.astype(np.float64)).reshape(16, 64, 64)
+    for (j, nt, p, hf, n32, e) in [(0, 0, 0, 0, 0, 0), (7, 1, 15, 1, 31, 3), (3, 0, 6, 1, 17, 2), (5, 1, 9, 0, 4, 1)]:
+        assert pk[j, nt, p, hf, n32, e] == np.float32(U[p, 32 * nt + n32, 8 * j + 4 * hf + e])
