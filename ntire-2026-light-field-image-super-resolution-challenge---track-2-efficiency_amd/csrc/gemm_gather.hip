@@ -240,6 +240,11 @@ int lfsr_angconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
   if (!x || !w1_packed || !w2_packed || !tmp || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < y_choff + 16 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   hipStream_t st = lfsr_stream(stream);
+  {
+    const char* sel = getenv("LFSR_ANG");   // LFSR_ANG=gather forces the two-launch gather-GEMM path (A/B runs)
+    if (!(sel && sel[0] == 'g') && lfsr_ang_fused_ok(A) && !((y_stride | y_choff) & 3))
+      return lfsr_ang_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, y_choff, B, A, h, w, slope, st);
+  }
   GemmArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w1_packed;
   p.Y = tmp; p.y_stride = 16; p.y_choff = 0;

@@ -25,6 +25,10 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
                              int n_img, int h, int w, float slope, hipStream_t st);
+// ang_fused.hip: the AngConv branch (conv AxA stride A 64->16, 1x1 16->16AA, PixelShuffle(A)) in one launch
+bool lfsr_ang_fused_ok(int A);
+int lfsr_ang_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* t, float* y,
+                          int y_stride, int y_choff, int B, int A, int h, int w, float slope, hipStream_t st);
 // epi_fused.hip  (t_h / t_v: optional (B*A*h*w, 32) buffers receiving the post-LeakyReLU stage-1 activations for backward)
 bool lfsr_epi_fused_ok(int A, int h, int w);
 int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,
