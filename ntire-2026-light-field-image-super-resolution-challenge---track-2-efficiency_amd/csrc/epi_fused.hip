@@ -31,9 +31,11 @@ struct EpiArgs {
   float slope;
 };
 
+// AT = 5: the BASELINE angular resolution, loops over views / taps fully unrolled; AT = 0: A read at run time (A = 1, 3)
+template <int AT>
 __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int A = p.A, PP = 32 + A - 1, pad = (A - 1) / 2;
+  const int A = AT ? AT : p.A, PP = 32 + A - 1, pad = (A - 1) / 2;
   float* sA = smem;                              // [LINES][PP][LROW]
   float* sW = smem + LINES * PP * LROW;          // [A][32][LROW]
   int* sLine = reinterpret_cast<int*>(sW + A * 32 * LROW);   // [LINES] source/dest base pixel or -1
@@ -98,7 +100,9 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
   const float* bBase = sW + l31 * LROW + 4 * half;
 
   prefetch(0);
-  for (int vv = 0; vv < A; ++vv) {
+#pragma unroll
+  for (int vv = 0; vv < (AT ? AT : 5); ++vv) {
+    if (vv >= A) break;
     if (vv > 0) __syncthreads();                    // previous stage fully consumed
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -112,7 +116,9 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
     }
     __syncthreads();
     if (vv + 1 < A) prefetch(vv + 1);               // flies under this stage's MFMAs
-    for (int dxi = 0; dxi < A; ++dxi) {
+#pragma unroll
+    for (int dxi = 0; dxi < (AT ? AT : 5); ++dxi) {
+      if (dxi >= A) break;
       const float* aT = aBase + dxi * LROW;
       const float* bT = bBase + dxi * 32 * LROW;
 #pragma unroll
@@ -163,16 +169,24 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].z, b.z, o, 0, 0, 0);
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].w, b.w, o, 0, 0, 0);
     }
+    // transpose the 32x32 tile through the wave-private LDS tile so that a lane stores 16 B (4 instructions of 8 positions x 128 B
+    // per chunk instead of 16 dword stores)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pos = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = o[r];
+      v = v >= 0.f ? v : v * p.slope;
+      sT[pos * TROW + l31] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
     if (base >= 0) {
       const long long dview = (long long)base + (long long)nt * vstride;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int pos = (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (pos < len) {
-          float v = o[r];
-          v = v >= 0.f ? v : v * p.slope;
-          p.Y[(dview + (long long)pos * pstride) * p.y_stride + choff + l31] = v;
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int pos = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
+        if (pos < len)
+          *reinterpret_cast<float4*>(p.Y + (dview + (long long)pos * pstride) * p.y_stride + choff + c4) = *reinterpret_cast<const float4*>(sT + pos * TROW + c4);
       }
     }
   }
@@ -197,7 +211,8 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   const int smem = (int)lfsr_epi_fused_smem(5);
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_fused), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_fused<5>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_fused<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
@@ -209,7 +224,8 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   p.tilesV = (which & 2) ? (B * A * w + LINES - 1) / LINES : 0;
   int grid = p.tilesH + p.tilesV;
   if (grid <= 0) return LFSR_E_ARG;
-  hipLaunchKernelGGL(k_epi_fused, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);
+  if (A == 5) hipLaunchKernelGGL(k_epi_fused<5>, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);
+  else hipLaunchKernelGGL(k_epi_fused<0>, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
