@@ -30,7 +30,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef WINO_ABL
-#define WINO_ABL 0   // diagnostic timing builds: 1 = no K-loop barriers, 2 = no halo streaming, 4 = no weight staging, 8 = no patch reads, 16 = half of them
+#define WINO_ABL 0   // diagnostic timing builds: 1 = no K-loop barriers, 2 = no halo streaming, 4 = no weight staging, 8 = no patch reads, 16 = half of them, 32 = patch reads from contiguous addresses
 #endif
 #ifdef LFSR_CONV_DIAG
 // diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   // 8 x 8 ds_read_b128 per CU holds up the B-fragment reads queued behind it -- LDS returns in order -- 4 do not)
   auto raw_read = [&](int j, int row, float4* raw) {
     const int o0 = ((2 * j) ^ k0) << 2, o1 = o0 ^ 16, o2 = ((2 * j) ^ k1) << 2, o3 = o2 ^ 16;
-    const float* hR = sH + (row == 0 ? offA : offB);
+    const float* hR = (WINO_ABL & 32) ? sH + (tid & 63) * 4 + row * 1024 + j * 2048 - o0 : sH + (row == 0 ? offA : offB);   // (timing ablation: contiguous 16 B per lane)
     raw[4 * row + 0] = *reinterpret_cast<const float4*>(hR + o0);
     raw[4 * row + 1] = *reinterpret_cast<const float4*>(hR + 64 + o1);
     raw[4 * row + 2] = *reinterpret_cast<const float4*>(hR + 128 + o2);

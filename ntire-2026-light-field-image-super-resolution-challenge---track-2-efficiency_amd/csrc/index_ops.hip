@@ -53,9 +53,20 @@ __global__ __launch_bounds__(256) void k_sai_macpi_lds(const float* __restrict__
   float* pout = out + plane * Hd * Wd;
   const int nvec = A * g_n * W4;    // float4 per side
   if (TO_MACPI) {
-    for (int i = threadIdx.x; i < nvec; i += 256) {           // SAI rows (u*h + y0+g) -> LDS [u][g][:]
-      int c4 = i % W4, r = i / W4, g = r % g_n, u = r / g_n;
-      *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = *reinterpret_cast<const float4*>(pin + (long long)(u * h + y0 + g) * Wd + c4 * 4);
+    // 4 loads in flight per thread before the first LDS store (a load-then-store loop waits for each load in turn)
+    for (int i0 = threadIdx.x; i0 < nvec; i0 += 1024) {      // SAI rows (u*h + y0+g) -> LDS [u][g][:]
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + 256 * q, ii = i < nvec ? i : 0;
+        const int c4 = ii % W4, r = ii / W4, g = r % g_n, u = r / g_n;
+        v[q] = *reinterpret_cast<const float4*>(pin + (long long)(u * h + y0 + g) * Wd + c4 * 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + 256 * q;
+        if (i < nvec) { const int c4 = i % W4, r = i / W4, g = r % g_n, u = r / g_n; *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = v[q]; }
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nvec; i += 256) {           // MacPI rows ((y0+g)*A + u), 4 consecutive columns
@@ -67,9 +78,19 @@ __global__ __launch_bounds__(256) void k_sai_macpi_lds(const float* __restrict__
       *reinterpret_cast<float4*>(pout + (long long)((y0 + g) * A + u) * Wd + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
   } else {
-    for (int i = threadIdx.x; i < nvec; i += 256) {           // MacPI rows -> LDS [u][g][x*A+v]
-      int c4 = i % W4, r = i / W4, u = r % A, g = r / A;
-      *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = *reinterpret_cast<const float4*>(pin + (long long)((y0 + g) * A + u) * Wd + c4 * 4);
+    for (int i0 = threadIdx.x; i0 < nvec; i0 += 1024) {      // MacPI rows -> LDS [u][g][x*A+v]
+      float4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + 256 * q, ii = i < nvec ? i : 0;
+        const int c4 = ii % W4, r = ii / W4, u = r % A, g = r / A;
+        v[q] = *reinterpret_cast<const float4*>(pin + (long long)((y0 + g) * A + u) * Wd + c4 * 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + 256 * q;
+        if (i < nvec) { const int c4 = i % W4, r = i / W4, u = r % A, g = r / A; *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = v[q]; }
+      }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nvec; i += 256) {           // SAI rows (u*h + y0+g)

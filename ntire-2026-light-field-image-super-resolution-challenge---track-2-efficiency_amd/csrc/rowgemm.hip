@@ -38,15 +38,22 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
   const int n0 = blockIdx.y * NB;
   const long long ntiles = (p.M + BMR - 1) / BMR;
 
-  // weight panel (rows beyond N are zero in the packed buffer's padding only up to Npad32: guard)
+  // weight panel (rows beyond N are zero in the packed buffer's padding only up to Npad32: guard).  All of a thread's loads are
+  // issued before its first LDS store: written as load-then-store per element the compiler waits for every load in turn
+  // (WL serial L2 round trips, ~6 us per launch)
+  {
+    float4 wv[WL];
 #pragma unroll
-  for (int i = 0; i < WL; ++i) {
-    int idx = tid + NTH * i;
-    if (idx < NB * CPR) {
-      int r = idx / CPR, c = idx - r * CPR;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + r < p.N) v = *reinterpret_cast<const float4*>(p.Wp + (long long)(n0 + r) * K + c * 4);
-      *reinterpret_cast<float4*>(sW + r * LR + c * 4) = v;
+    for (int i = 0; i < WL; ++i) {
+      const int idx = tid + NTH * i, r = idx / CPR, c = idx - r * CPR;
+      const bool ok = idx < NB * CPR && n0 + r < p.N;
+      const float4 v = *reinterpret_cast<const float4*>(p.Wp + (long long)(ok ? n0 + r : 0) * K + (ok ? c : 0) * 4);
+      wv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      const int idx = tid + NTH * i, r = idx / CPR, c = idx - r * CPR;
+      if (idx < NB * CPR) *reinterpret_cast<float4*>(sW + r * LR + c * 4) = wv[i];
     }
   }
 
