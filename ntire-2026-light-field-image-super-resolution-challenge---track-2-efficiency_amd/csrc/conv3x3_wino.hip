@@ -228,6 +228,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     const int next = tile + (int)gridDim.x;
     const bool has_next = !NHALF && next < p.ntiles;
     int nimg = 0, ny0 = 0, nx0 = 0;
+    int opix0[NOUT], opix1[NOUT];   // output pixels of the two epilogue rounds and round 0's prefetched operand: set up during the
+    float4 res[NOUT];               // last but one unit (its MFMAs cover the address arithmetic and the load latency; the patch registers are free)
     float4 V[4];
     if (WINO_ABL & 8) { V[0] = raw[0]; V[1] = raw[1]; V[2] = raw[2]; V[3] = raw[3]; }
 
@@ -309,6 +311,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
         nB01[1] = *reinterpret_cast<const float4*>(bn + 256);
       }
       __builtin_amdgcn_sched_barrier(0);   // LDS returns in order: the B fragments must not queue behind the 8 patch reads
+      if (u == NU - 2) {
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) {
+          opix0[i] = out_pixel(0, i, img, y0, x0);
+          opix1[i] = out_pixel(1, i, img, y0, x0);
+          if (has_e) res[i] = bload(rsE, opix0[i] >= 0 ? (opix0[i] * e_stride + e_choff + chunk_of(i) * 4) * 4 : OOB, 0);
+        }
+      }
       if (sfirst && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 0, raw);
       if (NHALF && j < 7 && !(WINO_ABL & 8)) raw_read(j + 1, 1, raw);
       if (!NHALF && slast && j < 7 && !(WINO_ABL & 8)) transform(raw, nV);   // in the shadow of this unit's last 8 and the next unit's first 8 MFMAs
@@ -339,14 +349,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
     }
     // output pixels of both rounds; the prefetched operand (residual / LeakyReLU' mask) of a round is requested before any
     // store of the previous round is queued (vmcnt retires in order: a load behind the stores would wait for them)
-    int opix0[NOUT], opix1[NOUT];
-    float4 res[NOUT];
-#pragma unroll
-    for (int i = 0; i < NOUT; ++i) {
-      opix0[i] = out_pixel(0, i, img, y0, x0);
-      opix1[i] = out_pixel(1, i, img, y0, x0);
-      if (has_e) res[i] = bload(rsE, opix0[i] >= 0 ? (opix0[i] * e_stride + e_choff + chunk_of(i) * 4) * 4 : OOB, 0);
-    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       int* opix = b == 0 ? opix0 : opix1;
