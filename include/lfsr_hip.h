@@ -189,6 +189,12 @@ int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* p
 int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const float* w_packed, const float* bias,
                     const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
                     long long M, int N, float slope, void* stream);
+/* Fused feed-forward block of the transformers (EPIT.py:84-90,126; LFT.py:151-156,202,216-221,243):
+ *   y = res + W2 . act(W1 . x)      x: (M, K1) LayerNorm'd tokens, W1 (H, K1), W2 (N2, H) packed as for lfsr_linear_fwd, no biases;
+ * the (M, H) hidden activations stay on chip.  (K1, N2) in {(128,128), (64,64)}, H a multiple of 32; slope 0 = ReLU. */
+int lfsr_ffn_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                 const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
+                 long long M, int K1, int H, int N2, float slope, void* stream);
 /* nn.MultiheadAttention core with the reference's additive window mask evaluated as a predicate (EPIT.py:93-122,
  * LFT.py:161-199,238-241): o = softmax(q k^T / sqrt(hd) + mask) v per head; hd in {8,16}.
  * Sequences (s0,s1,s2) start at pixel s0*bs0+s1*bs1+s2*bs2; token (t1,t2) sits at + t1*st1 + t2*st2; token (t1,t2)

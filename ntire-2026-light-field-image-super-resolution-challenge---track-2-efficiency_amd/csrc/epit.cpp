@@ -108,8 +108,12 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
     if (r) return r;
     if ((r = lfsr_linear_fwd(TN, 128, 0, 128, P.w(e + "attention.out_proj.weight"), nullptr, T, 128, 0, T2, 128, 0, npix, 128, 1.0f, stream))) return r;
     if ((r = lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, P.w(e + "feed_forward.0.weight"), P.w(e + "feed_forward.0.bias"), V, 128, 0, npix, 128, 1e-5f, stream))) return r;
-    if ((r = lfsr_linear_fwd(V, 128, 0, 128, P.w(e + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream))) return r;   // ReLU
-    if ((r = lfsr_linear_fwd(QK, 256, 0, 256, P.w(e + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream))) return r;
+    if (getenv("LFSR_NO_FFN_FUSED")) {   // two-launch form (A/B runs): the hidden activations go through HBM
+      if ((r = lfsr_linear_fwd(V, 128, 0, 128, P.w(e + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream))) return r;   // ReLU
+      if ((r = lfsr_linear_fwd(QK, 256, 0, 256, P.w(e + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream))) return r;
+    } else if ((r = lfsr_ffn_fwd(V, 128, 0, P.w(e + "feed_forward.1.weight"), P.w(e + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0, npix, 128, 256, 128, 0.0f, stream))) {
+      return r;
+    }
     return lfsr_linear_fwd(T, 128, 0, 128, P.w(e + "linear_out.weight"), nullptr, nullptr, 0, 0, Yo, 64, 0, npix, 64, 1.0f, stream);
   };
 

@@ -201,25 +201,45 @@ __global__ __launch_bounds__(256) void k_gemm_gather(GemmArgs p) {
     }
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Per column tile: destination pixels first, then every optional operand load (mask, residuals) of the 16 elements back to
+  // back, then the arithmetic and the stores -- written as load-use-store per element, each load was waited for in turn
+  // (16 serial memory round trips per tile and wave)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (m >= p.M) continue;
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + t * 32 + l31;
+    const bool ncol = n < p.N;
+    int chunk = 0, c = n;
+    if (OUT != OUT_SAME && ncol) { chunk = n / p.CH; c = n - chunk * p.CH; }
+    const float bs = (p.bias && ncol) ? p.bias[n] : 0.f;
+    long long dp[16];
+    float mk[16], r1[16], r2[16];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = n0 + t * 32 + l31;
-      if (n >= p.N) continue;
-      float v = acc[t][r];
-      if (p.bias) v += p.bias[n];
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      dp[r] = (ncol && m < p.M) ? dst_pixel<OUT>(m, chunk, p) : -1;
+    }
+    if (p.Mk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mk[r] = dp[r] >= 0 ? p.Mk[dp[r] * p.mk_stride + p.mk_choff + c] : 1.f;
+    }
+    if (p.R1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) r1[r] = dp[r] >= 0 ? p.R1[dp[r] * p.r1_stride + p.r1_choff + c] : 0.f;
+    }
+    if (p.R2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) r2[r] = dp[r] >= 0 ? p.R2[dp[r] * p.r2_stride + p.r2_choff + c] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (dp[r] < 0) continue;
+      float v = acc[t][r] + bs;
       v = v >= 0.f ? v : v * p.slope;
-      int chunk = 0, c = n;
-      if (OUT != OUT_SAME) { chunk = n / p.CH; c = n - chunk * p.CH; }
-      const long long dp = dst_pixel<OUT>(m, chunk, p);
-      if (p.Mk) v *= (p.Mk[dp * p.mk_stride + p.mk_choff + c] > 0.f) ? 1.f : p.mk_slope;
-      if (p.R1) v += p.R1[dp * p.r1_stride + p.r1_choff + c];
-      if (p.R2) v += p.R2[dp * p.r2_stride + p.r2_choff + c];
-      p.Y[dp * p.y_stride + p.y_choff + c] = v;
+      if (p.Mk) v *= mk[r] > 0.f ? 1.f : p.mk_slope;
+      if (p.R1) v += r1[r];
+      if (p.R2) v += r2[r];
+      p.Y[dp[r] * p.y_stride + p.y_choff + c] = v;
     }
   }
 }

@@ -118,6 +118,7 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
   RC(conv(C2, "conv_init.4.weight", BUF0, F0, L));                         // LFT.py:81
   RC(lfsr_lft_position_fwd(SPOS, APE, A, h, w, 64, stream));              // LFT.py:84-85
   const float* cur = BUF0;
+  const bool no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;   // two-launch feed-forward (A/B runs)
   for (int b = 0; b < c->nlayer; ++b) {
     // ---- AngTrans (LFT.py:233-246): tokens = the A*A views at one (y, x); E = 64, 8 heads of 8, no mask -----------
     std::string an = "altblock." + std::to_string(b) + ".ang_trans.";
@@ -130,8 +131,12 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
                             AA, 1, HW, 0, AA, AA, 0, 1, 0, stream));
     RC(lfsr_linear_fwd(C2, 64, 0, 64, P.w(an + "attention.out_proj.weight"), nullptr, cur, 64, 0, C1, 64, 0, npix, 64, 1.0f, stream));     // + token
     RC(lfsr_layernorm_fwd(C1, 64, 0, nullptr, 0, 0, 1, P.w(an + "feed_forward.0.weight"), P.w(an + "feed_forward.0.bias"), N64, 64, 0, npix, 64, 1e-5f, stream));
-    RC(lfsr_linear_fwd(N64, 64, 0, 64, P.w(an + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 0.0f, stream));     // ReLU
-    RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(an + "feed_forward.4.weight"), nullptr, C1, 64, 0, a_out, 64, 0, npix, 64, 1.0f, stream));
+    if (no_ffn_fused) {
+      RC(lfsr_linear_fwd(N64, 64, 0, 64, P.w(an + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 0.0f, stream));     // ReLU
+      RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(an + "feed_forward.4.weight"), nullptr, C1, 64, 0, a_out, 64, 0, npix, 64, 1.0f, stream));
+    } else {
+      RC(lfsr_ffn_fwd(N64, 64, 0, P.w(an + "feed_forward.1.weight"), P.w(an + "feed_forward.4.weight"), C1, 64, 0, a_out, 64, 0, npix, 64, 128, 64, 0.0f, stream));
+    }
     // ---- SpaTrans (LFT.py:188-203): tokens = the h*w positions of one view; E = 128, 8 heads of 16, 5x5 window --------
     std::string sp = "altblock." + std::to_string(b) + ".spa_trans.";
     float* s_out = (a_out == Pb) ? Qb : Pb;
@@ -146,8 +151,12 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
     RC(lfsr_window_attn_fwd(QK, 256, 0, QK, 256, 128, V, 128, 0, TN, 128, 0, 8, 16, nimg, 1, 1, HW, 0, 0, h, w, w, 1, 2, 3, 2, 3, h, stream));
     RC(lfsr_linear_fwd(TN, 128, 0, 128, P.w(sp + "attention.out_proj.weight"), nullptr, T, 128, 0, T2, 128, 0, npix, 128, 1.0f, stream));
     RC(lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, P.w(sp + "feed_forward.0.weight"), P.w(sp + "feed_forward.0.bias"), V, 128, 0, npix, 128, 1e-5f, stream));
-    RC(lfsr_linear_fwd(V, 128, 0, 128, P.w(sp + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream));
-    RC(lfsr_linear_fwd(QK, 256, 0, 256, P.w(sp + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream));
+    if (no_ffn_fused) {
+      RC(lfsr_linear_fwd(V, 128, 0, 128, P.w(sp + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream));
+      RC(lfsr_linear_fwd(QK, 256, 0, 256, P.w(sp + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream));
+    } else {
+      RC(lfsr_ffn_fwd(V, 128, 0, P.w(sp + "feed_forward.1.weight"), P.w(sp + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0, npix, 128, 256, 128, 0.0f, stream));
+    }
     // Conv3d 1x1x1 128 -> 64 (LFT.py:183-186); the network-level skip (LFT.py:91) rides on the last layer's projection
     const bool last = b == c->nlayer - 1;
     RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(sp + "linear.0.weight"), nullptr, last ? BUF0 : nullptr, 64, 0, s_out, 64, 0, npix, 64, 1.0f, stream));

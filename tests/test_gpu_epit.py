@@ -50,6 +50,25 @@ def test_linear(cin, N, slope):
     assert np.abs(y.cpu().numpy() - ref).max() < ATOL
 
 
+@pytest.mark.parametrize("K1,H,M", [(128, 256, 777), (64, 128, 2100), (128, 256, 70000)])
+def test_ffn_fused(K1, H, M):
+    """y = res + W2 relu(W1 x): the fused feed-forward block (EPIT.py:84-90,126; LFT.py:151-156,216-221) against fp64 numpy"""
+    lib = capi.load()
+    x, w1, w2, r = rnd((M, K1), 14), rnd((H, K1), 15, 0.1), rnd((K1, H), 16, 0.1), rnd((M, K1), 17)
+    y = torch.empty(M, K1, device="cuda")
+    xd, rd = dev(x), dev(r)
+    w1p = capi.pack_conv_weight(dev(w1.reshape(H, K1, 1, 1)))
+    w2p = capi.pack_conv_weight(dev(w2.reshape(K1, H, 1, 1)))
+    capi.check(lib.lfsr_ffn_fwd(capi.dev_ptr(xd), K1, 0, capi.dev_ptr(w1p), capi.dev_ptr(w2p), capi.dev_ptr(rd), K1, 0,
+                                capi.dev_ptr(y), K1, 0, M, K1, H, K1, 0.0, capi.stream_ptr()), "ffn")
+    hid = np.maximum(x.astype(np.float64) @ w1.astype(np.float64).T, 0.0)
+    ref = hid @ w2.astype(np.float64).T + r
+    assert np.abs(y.cpu().numpy() - ref).max() < ATOL
+    # unsupported shapes are refused, not silently mis-computed
+    assert lib.lfsr_ffn_fwd(capi.dev_ptr(xd), K1, 0, capi.dev_ptr(w1p), capi.dev_ptr(w2p), None, 0, 0,
+                            capi.dev_ptr(y), K1, 0, M, K1, H + 8, K1, 0.0, capi.stream_ptr()) == -1
+
+
 @pytest.mark.parametrize("vertical", [0, 1])
 def test_epi_attention_vs_masked_mha(vertical):
     """window predicate == the reference's additive -inf mask (EPIT.py:93-108) inside nn.MultiheadAttention's core"""
