@@ -39,6 +39,7 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
   float* sA = smem;                              // [LINES][PP][LROW]
   float* sW = smem + LINES * PP * LROW;          // [A][32][LROW]
   int* sLine = reinterpret_cast<int*>(sW + A * 32 * LROW);   // [LINES] source/dest base pixel or -1
+  float* sW2 = reinterpret_cast<float*>(sLine + LINES + 4);   // [32A][TROW]: the 1x1 weights, staged once per block (16-B aligned)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = tid & 15, r16 = tid >> 4;
@@ -63,6 +64,19 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
       else { int b = q / A, v = q - b * A; base = (b * A * A + v) * HW + o; }
     }
     sLine[tid] = base;
+  }
+  {   // 1x1 weights -> LDS (rows padded to TROW floats): all loads of a thread issued before its first store
+    float4 wv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 512 * q;
+      wv[q] = idx < A * 32 * 8 ? reinterpret_cast<const float4*>(p.W2)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 512 * q;
+      if (idx < A * 32 * 8) *reinterpret_cast<float4*>(sW2 + (idx >> 3) * TROW + (idx & 7) * 4) = wv[q];
+    }
   }
   __syncthreads();
 
@@ -163,7 +177,7 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float4 b = *reinterpret_cast<const float4*>(p.W2 + (nt * 32 + l31) * 32 + 8 * j + 4 * half);   // 20 KB, L1/L2 resident
+      float4 b = *reinterpret_cast<const float4*>(sW2 + (nt * 32 + l31) * TROW + 8 * j + 4 * half);
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].x, b.x, o, 0, 0, 0);
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].y, b.y, o, 0, 0, 0);
       o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].z, b.z, o, 0, 0, 0);
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
 }  // namespace
 
 size_t lfsr_epi_fused_smem(int A) {
-  return (size_t)(LINES * (32 + A - 1) * LROW + A * 32 * LROW) * 4 + LINES * 4 + 32;
+  return (size_t)(LINES * (32 + A - 1) * LROW + A * 32 * LROW) * 4 + (LINES + 4) * 4 + (size_t)A * 32 * TROW * 4;
 }
 
 bool lfsr_epi_fused_ok(int A, int h, int w) {

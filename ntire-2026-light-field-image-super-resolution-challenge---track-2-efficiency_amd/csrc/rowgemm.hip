@@ -100,30 +100,45 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
       }
     }
-    // epilogue straight from the accumulators: a store instruction covers 32 consecutive channels of two rows.  The residual
-    // loads of a column tile are issued back to back before the first use (per element they were waited for one by one)
+    // epilogue straight from the accumulators: a store instruction covers 32 consecutive channels of two rows
     const long long m0 = tile * BMR;
+    if (!p.R1) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = n0 + ng * (NB / 2) + t * 32 + l31;
-      const bool ncol = n < p.N;
-      const float bs = (p.bias && ncol) ? p.bias[n] : 0.f;
-      float rv[16];
-      if (p.R1) {
+      for (int r = 0; r < 16; ++r) {
+        const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int n = n0 + ng * (NB / 2) + t * 32 + l31;
+          if (n >= p.N) continue;
+          float v = acc[t][r];
+          if (p.bias) v += p.bias[n];
+          v = v >= 0.f ? v : v * p.slope;
+          p.Y[m * p.y_stride + p.y_choff + n] = v;
+        }
+      }
+    } else {
+      // with a residual operand: its loads of a column tile are issued back to back before the first use (per element they
+      // were waited for one by one)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n = n0 + ng * (NB / 2) + t * 32 + l31;
+        const bool ncol = n < p.N;
+        const float bs = (p.bias && ncol) ? p.bias[n] : 0.f;
+        float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           rv[r] = (ncol && m < p.M) ? p.R1[m * p.r1_stride + p.r1_choff + n] : 0.f;
         }
-      }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.M || !ncol) continue;
-        float v = acc[t][r] + bs;
-        v = v >= 0.f ? v : v * p.slope;
-        if (p.R1) v += rv[r];
-        p.Y[m * p.y_stride + p.y_choff + n] = v;
+        for (int r = 0; r < 16; ++r) {
+          const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (m >= p.M || !ncol) continue;
+          float v = acc[t][r] + bs;
+          v = v >= 0.f ? v : v * p.slope;
+          p.Y[m * p.y_stride + p.y_choff + n] = v + rv[r];
+        }
       }
     }
     __syncthreads();   // everyone is done with sA before the next tile's rows overwrite it
