@@ -57,19 +57,27 @@ __global__ __launch_bounds__(512) void k_up_tail(UpTailArgs p) {
 
   // ---- stage the F halo tile (zero outside the mosaic), w3, and weight chunk 0 ------------------------------------------
   for (int i = tid; i < 64 * 9; i += 512) sW3[i] = p.W3[i];
-  for (int idx = tid; idx < UT_ROWS * 16; idx += 512) {
-    int px = idx >> 4, ch = idx & 15;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (px < UT_PIX) {
-      int ly = px / (UT_X + 2), lx = px - ly * (UT_X + 2);
-      int Ym = Y0 + ly - 1, Xm = X0 + lx - 1;
-      if (Ym >= 0 && Ym < Hm && Xm >= 0 && Xm < Wm) {
-        int u = Ym / p.h, y = Ym - u * p.h, vv = Xm / p.w, x = Xm - vv * p.w;
-        long long pix = ((long long)b * p.A * p.A + u * p.A + vv) * HW + (long long)y * p.w + x;
-        v = *reinterpret_cast<const float4*>(p.F + pix * p.f_stride + p.f_choff + ch * 4);
+  {   // 7 float4 per thread, all loads issued before the first LDS store (a load-store loop waits for each load in turn)
+    float4 fv[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int idx = tid + 512 * q, px = idx >> 4, ch = idx & 15;
+      fv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (px < UT_PIX) {
+        int ly = px / (UT_X + 2), lx = px - ly * (UT_X + 2);
+        int Ym = Y0 + ly - 1, Xm = X0 + lx - 1;
+        if (Ym >= 0 && Ym < Hm && Xm >= 0 && Xm < Wm) {
+          int u = Ym / p.h, y = Ym - u * p.h, vv = Xm / p.w, x = Xm - vv * p.w;
+          long long pix = ((long long)b * p.A * p.A + u * p.A + vv) * HW + (long long)y * p.w + x;
+          fv[q] = *reinterpret_cast<const float4*>(p.F + pix * p.f_stride + p.f_choff + ch * 4);
+        }
       }
     }
-    *reinterpret_cast<float4*>(sF + px * LDS_ROW + ch * 4) = v;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int idx = tid + 512 * q;
+      *reinterpret_cast<float4*>(sF + (idx >> 4) * LDS_ROW + (idx & 15) * 4) = fv[q];
+    }
   }
   // weight chunk cc: LDS row (dc*S2 + ij) <- packed row (ij*64 + cc*CC + dc)
   auto wrow = [&](int cc, int r) -> const float* { int dc = r / S2, ij = r - dc * S2; return p.W0p + ((long long)(ij * 64 + cc * CC + dc)) * 64; };
