@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/pmc_conv3x3.json from two rocprofv3 PMC passes of bench.py (FETCH_SIZE and WRITE_SIZE, csv output) and the
 --kernel-trace --stats pass: HBM bytes per 3x3 conv op = body launch + channel-split tail launch of the Winograd kernel.
-usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel_stats.csv> <out.json>"""
+usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel_stats.csv> <out.json> [all_kernels.json]"""
 import csv, json, sys
 from collections import defaultdict
 
@@ -37,4 +37,10 @@ for r in csv.DictReader(open(stats)):
         us += float(r["AverageNs"]) / 1000.0
 res["rocprof_avg_us_per_op"] = us
 json.dump(res, open(out, "w"), indent=1)
+if len(sys.argv) > 5:   # optional: every kernel's HBM bytes per launch (same correction) -> profiles/r01_pmc_traffic.json
+    allk = {}
+    for k in sorted(set(F) | set(W)):
+        f, n = F.get(k, (0.0, 0)); w, _ = W.get(k, (0.0, 0))
+        allk[k] = {"launches": n, "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    json.dump(allk, open(sys.argv[5], "w"), indent=1)
 print(json.dumps(res, indent=1))
