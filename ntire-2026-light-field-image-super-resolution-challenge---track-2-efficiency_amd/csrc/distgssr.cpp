@@ -32,6 +32,7 @@ struct lfsr_distgssr {
   bool finalized = false;
   bool profiling = false;
   struct Ev { int cls; hipEvent_t a, b; };
+  bool profile_all = true;
   std::vector<Ev> evs;          // recorded this profiling session
   std::vector<hipEvent_t> free_evs;
   hipEvent_t get_ev() {
@@ -105,6 +106,7 @@ int lfsr_distgssr_profile(lfsr_distgssr* c, int enable) {
   for (auto& e : c->evs) { c->free_evs.push_back(e.a); c->free_evs.push_back(e.b); }
   c->evs.clear();
   c->profiling = enable != 0;
+  c->profile_all = enable != 2;   // enable = 2: events around the 3x3 conv ops only (class 0), the cheapest live measurement
   return LFSR_OK;
 }
 
@@ -207,7 +209,7 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
 #define PROF(cls, call)                                                              \
   do {                                                                               \
-    if (c->profiling) {                                                              \
+    if (c->profiling && (c->profile_all || (cls) == 0)) {                            \
       lfsr_distgssr::Ev ev{cls, c->get_ev(), c->get_ev()};                           \
       (void)hipEventRecord(ev.a, lfsr_stream(stream));                                     \
       rc = (call);                                                                   \
