@@ -251,6 +251,13 @@ int lfsr_view_metrics(const float* label, const float* out, double* psnr, double
  * (device bytes) filled with `fill` ('zero' / 'mean' strategies; the reference applies one mask to the whole batch). */
 int lfsr_mask_views(const float* x, float* y, const unsigned char* mask, float fill, int B, int C, int A, int h, int w, void* stream);
 
+/* N4, output tail of test() (train.py:329-341, inference.py:205-216; utils/utils.py:191-204 ycbcr2rgb):
+ * out[(u, v, y, x, c)] = uint8(clip(M255 . (Y, Cb, Cr) - offset, 0, 1) * 255), evaluated in fp64 like the reference's numpy path.
+ * y (A*h, A*w) and cbcr (2, A*h, A*w) fp32 SAI mosaics; minv255 = inv(M) * 255 (row-major 3x3) and offset = inv(M) . (16,128,128),
+ * both computed by the caller exactly as the reference does; out: (A, A, h, w, 3) uint8. */
+int lfsr_ycbcr2rgb_views(const float* y, const float* cbcr, unsigned char* out, int A, int h, int w, const double* minv255,
+                         const double* offset, void* stream);
+
 /* Whole-model driver: LF_InterNet forward (get_model.forward, LF_InterNet.py:33-41); n_groups = n_layers = 4 upstream. */
 typedef struct lfsr_internet lfsr_internet;
 int lfsr_internet_create(lfsr_internet** ctx, int A, int scale, int n_groups, int n_layers);

@@ -94,6 +94,31 @@ __global__ __launch_bounds__(256) void k_mask_views(const float* __restrict__ x,
   }
 }
 
+
+// "Next" row N4 of SURVEY 8f, the output tail of test() (train.py:329-341, inference.py:205-216; utils/utils.py:191-204):
+//   rgb = uint8( clip( ycbcr2rgb(cat(Sr_SAI_y, Sr_SAI_cbcr)), 0, 1 ) * 255 ),  split into A x A views (h, w, 3)
+// The reference does this on the CPU in float64 (numpy); here one thread per mosaic pixel evaluates the same affine map in
+// fp64 with the host-computed inverse matrix (same operation order) and writes the view-major (A, A, h, w, 3) uint8 tensor
+// that the BMP writer consumes, so the 13 MB mosaic never crosses PCIe as floats.
+__global__ __launch_bounds__(256) void k_ycbcr2rgb_views(const float* __restrict__ yp, const float* __restrict__ cbcr, unsigned char* __restrict__ out,
+                                                        int A, int h, int w, double m00, double m01, double m02, double m10, double m11, double m12,
+                                                        double m20, double m21, double m22, double o0, double o1, double o2) {
+  const long long Hm = (long long)A * h, Wm = (long long)A * w, npix = Hm * Wm;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+    const long long Y = i / Wm, X = i - Y * Wm;
+    const double c0 = (double)yp[i], c1 = (double)cbcr[i], c2 = (double)cbcr[npix + i];
+    // explicit round-to-nearest multiplies and adds in numpy's order: no fma contraction, so the uint8 truncation below sees
+    // bit-identical doubles
+    double r = __dsub_rn(__dadd_rn(__dadd_rn(__dmul_rn(m00, c0), __dmul_rn(m01, c1)), __dmul_rn(m02, c2)), o0);
+    double g = __dsub_rn(__dadd_rn(__dadd_rn(__dmul_rn(m10, c0), __dmul_rn(m11, c1)), __dmul_rn(m12, c2)), o1);
+    double b = __dsub_rn(__dadd_rn(__dadd_rn(__dmul_rn(m20, c0), __dmul_rn(m21, c1)), __dmul_rn(m22, c2)), o2);
+    r = __dmul_rn(fmin(fmax(r, 0.0), 1.0), 255.0); g = __dmul_rn(fmin(fmax(g, 0.0), 1.0), 255.0); b = __dmul_rn(fmin(fmax(b, 0.0), 1.0), 255.0);
+    const int u = (int)(Y / h), y = (int)(Y - (long long)u * h), v = (int)(X / w), x = (int)(X - (long long)v * w);
+    unsigned char* o = out + ((((long long)u * A + v) * h + y) * w + x) * 3;
+    o[0] = (unsigned char)r; o[1] = (unsigned char)g; o[2] = (unsigned char)b;   // astype('uint8'): truncation
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -124,3 +149,14 @@ int lfsr_mask_views(const float* x, float* y, const unsigned char* mask, float f
 }
 
 }  // extern "C"
+
+extern "C" int lfsr_ycbcr2rgb_views(const float* y, const float* cbcr, unsigned char* out, int A, int h, int w, const double* minv255,
+                                    const double* offset, void* stream) {
+  if (!y || !cbcr || !out || !minv255 || !offset || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
+  const long long npix = (long long)A * h * A * w;
+  hipLaunchKernelGGL(k_ycbcr2rgb_views, dim3(lfsr_blocks(npix, 256)), dim3(256), 0, lfsr_stream(stream), y, cbcr, out, A, h, w,
+                     minv255[0], minv255[1], minv255[2], minv255[3], minv255[4], minv255[5], minv255[6], minv255[7], minv255[8],
+                     offset[0], offset[1], offset[2]);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

@@ -590,3 +590,24 @@ def conv3x3_winograd(x, w):
             M = np.einsum("aboc,abnc->abno", U, V)
             y[:, :, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ia,abno,jb->noij", AT, M, AT)
     return y
+
+
+# ---- N4 output tail (utils/utils.py:191-204 ycbcr2rgb; train.py:329-341) ------------------------------------------------------
+def ycbcr2rgb(x):
+    """(H, W, 3) YCbCr in [0, 1] -> RGB (float64): the reference's formula, operation for operation"""
+    mat = np.array([[65.481, 128.553, 24.966], [-37.797, -74.203, 112.0], [112.0, -93.786, -18.214]])
+    mat_inv = np.linalg.inv(mat)
+    offset = np.matmul(mat_inv, np.array([16, 128, 128]))
+    mat_inv = mat_inv * 255
+    y = np.zeros(x.shape, dtype="double")
+    for i in range(3):
+        y[:, :, i] = mat_inv[i, 0] * x[:, :, 0] + mat_inv[i, 1] * x[:, :, 1] + mat_inv[i, 2] * x[:, :, 2] - offset[i]
+    return y
+
+
+def sr_views_rgb_u8(sr_y, sr_cbcr, A):
+    """(A h, A w) Y and (2, A h, A w) CbCr -> (A, A, h, w, 3) uint8, as train.py:332-334 builds Sr_4D_rgb"""
+    ycc = np.concatenate([sr_y[None], sr_cbcr], axis=0).transpose(1, 2, 0)
+    rgb = (ycbcr2rgb(ycc).clip(0, 1) * 255).astype("uint8")
+    H, W, _ = rgb.shape
+    return rgb.reshape(A, H // A, A, W // A, 3).transpose(0, 2, 1, 3, 4)
