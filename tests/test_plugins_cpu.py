@@ -36,3 +36,21 @@ def test_losses():
     E = importlib.import_module("lfsr_amd.model.SR.EPIT")
     with pytest.raises((TypeError, IndexError)):                              # upstream quirk kept: out['SR'] on a tensor
         E.get_loss(None)(torch.ones(1, 1, 2, 2), torch.zeros(1, 1, 2, 2))
+
+
+def test_h5_layout_roundtrip():
+    """N4: the transposed on-disk layout of the test scenes (Generate_Data_for_Test.py:88-92 / utils_datasets.py:111-128)"""
+    import numpy as np
+    from lfsr_amd.utils.h5_layout import from_h5_arrays, to_h5_arrays
+    rng = np.random.default_rng(3)
+    lr, hr, cc = rng.random((10, 15)), rng.random((20, 30)), rng.random((20, 30, 2))
+    s_lr, s_hr, s_cc = to_h5_arrays(lr, hr, cc)
+    assert s_lr.shape == (15, 10) and s_hr.shape == (30, 20) and s_cc.shape == (2, 30, 20) and s_cc.dtype == np.float32
+    t_lr, t_hr, t_cc = from_h5_arrays(s_lr, s_hr, s_cc)
+    assert t_lr.shape == (1, 10, 15) and t_hr.shape == (1, 20, 30) and t_cc.shape == (2, 20, 30)
+    assert np.allclose(t_lr[0].numpy(), lr.astype(np.float32)) and np.allclose(t_cc.numpy(), cc.astype(np.float32).transpose(2, 0, 1))
+    # degenerate chroma as the reference handles it
+    _, _, z = from_h5_arrays(s_lr, s_hr, np.zeros((), dtype=np.float32))
+    assert z.shape == (2, 20, 30) and float(z.abs().max()) == 0.0
+    _, _, one = from_h5_arrays(s_lr, s_hr, rng.random((20, 30)).astype(np.float32))
+    assert one.shape == (1, 20, 30)
