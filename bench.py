@@ -189,7 +189,7 @@ def main():
         exec_flop = conv_flop if direct else tiles * 16 * 2.0 * 64 * 64 * 64
         kname = ("k_conv3x3_halo (direct 9-tap halo-tile kernel + channel-split tail launch)" if direct else
                  "k_conv3x3_wino (per-view 3x3 64->64 in Winograd F(2x2,3x3) form: persistent 8x32 tiles, 16 position-GEMMs on fp32 MFMA "
-                 "32x32x2, in-place halo streaming; body launch + channel-split tail launch of the same kernel)")
+                 "32x32x2, in-place halo streaming; one launch: persistent body blocks + channel-split blocks for the leftover tiles)")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
         if os.path.exists(pmc):
@@ -207,7 +207,7 @@ def main():
                        "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": kname + "; duration = both launches of one conv op",
+                         "kernel": kname + "; duration = one conv op",
                          "flop_per_launch": conv_flop, "executed_flop_per_launch": exec_flop,
                          "mfma_util": exec_flop / (conv_avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                          "note": "achieved = algorithmic direct-conv flops (SURVEY 8d) / time; the Winograd form issues 2.25x fewer MFMA "

@@ -56,7 +56,8 @@ struct WinoArgs {
   const float* R2; int r2_stride; int r2_choff;
   const float* Mk; int mk_stride; int mk_choff; float mk_slope;
   int n_img, H, W, tiles_y, tiles_x, ntiles;
-  int tile_begin;   // NHALF launch: first tile of its range
+  int tile_begin;   // channel-split blocks: first tile of their range (set by the kernel)
+  int nbody;        // number of persistent body blocks in the launch
   float slope;
 };
 
@@ -95,10 +96,10 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, int voff, float
 // each, block (2t + nh) computing output channels [32 nh, 32 nh + 32) of tile t: one N-tile per wave, 8 units instead of 16
 // (half the MFMAs, ~0.55 of a tile time), one tile per block.
 template <bool MASK, bool NHALF>
-__global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
+__device__ __forceinline__ void wino_tile_loop(WinoArgs p, const int bid, const int nblk) {   // bid of nblk blocks of this role
   constexpr int NU = NHALF ? 8 : 16;           // units per tile
   constexpr int NOUT = NHALF ? 2 : 4;          // epilogue outputs (float4) per thread and round
-  const int nh = NHALF ? (int)(blockIdx.x & 1) : 0;
+  const int nh = NHALF ? (bid & 1) : 0;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sH = smem;                  // halo
   float* sR = smem + HALO_FLOATS;    // weight ring (3 units) / epilogue exchange
@@ -187,11 +188,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   };
 
   auto chunk_of = [&](int i) -> int { const int o = vtid + 512 * i; return NHALF ? (o & 7) + 8 * nh : (o & 15); };   // 16-B channel chunk of output i
-  int tile = NHALF ? p.tile_begin + (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  int tile = NHALF ? p.tile_begin + (bid >> 1) : bid;
   int img, y0, x0;
   tile_origin(tile, img, y0, x0);
   // the persistent stride gridDim.x as (images, tile rows, tile columns): the next tile's origin by carries, no divisions
-  const int g_tx = (int)gridDim.x % p.tiles_x, g_q = (int)gridDim.x / p.tiles_x;
+  const int g_tx = nblk % p.tiles_x, g_q = nblk / p.tiles_x;
   const int g_ty = g_q % p.tiles_y, g_img = g_q / p.tiles_y;
 
   // ---- prologue: whole halo of the first tile, unit 0 into the ring, unit 1 in registers --------------------------
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   while (true) {
-    const int next = tile + (int)gridDim.x;
+    const int next = tile + nblk;
     const bool has_next = !NHALF && next < p.ntiles;
     int nimg = 0, ny0 = 0, nx0 = 0;
     int opix0[NOUT], opix1[NOUT];   // output pixels of the two epilogue rounds and round 0's prefetched operand: set up during the
@@ -419,8 +420,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
   }
 #ifdef LFSR_CONV_DIAG
   if (dbgbuf && tid == 0)
-    for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
+    for (int k = 0; k < 32; ++k) dbgbuf[bid * 32 + k] = (float)seg[k];
 #endif
+}
+
+// One launch per conv op: blocks [0, nbody) are the persistent body blocks (tiles [0, ntiles)), blocks [nbody, nbody + 2 ntail)
+// the channel-split blocks of the leftover tiles -- they are dispatched as body blocks retire, without a second launch's latency.
+template <bool MASK>
+__global__ __launch_bounds__(512) void k_conv3x3_wino(WinoArgs p) {
+  if ((int)blockIdx.x < p.nbody) {
+    wino_tile_loop<MASK, false>(p, (int)blockIdx.x, p.nbody);
+  } else {
+    p.tile_begin = p.ntiles;
+    wino_tile_loop<MASK, true>(p, (int)blockIdx.x - p.nbody, 0);
+  }
 }
 
 // U = G g G^t per (n, k) from the direct pack [tap][n][k] -> [j = k/8][nt = n/32][p][half = (k/4)&1][n%32][k%4]
@@ -467,10 +480,8 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     int v = 0;
     cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
@@ -505,18 +516,14 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
   const bool tail_direct = tsel && tsel[0] == 'h' && w_direct;
   const int body = (int)nblk - tail;
   p.ntiles = body;
-  const unsigned grid = (unsigned)(body < ncu ? body : ncu);
-  if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  else hipLaunchKernelGGL((k_conv3x3_wino<false, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  p.nbody = body < ncu ? body : ncu;
+  const int wino_tail = tail_direct ? 0 : tail;
+  const unsigned grid = (unsigned)(p.nbody + 2 * wino_tail);
+  if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((k_conv3x3_wino<false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
   LFSR_CHECK_LAUNCH();
   if (tail > 0 && tail_direct)
     return lfsr_conv3x3_halo_tail_launch(x, x_stride, x_choff, w_direct, y, y_stride, y_choff, r1, r1_stride, r1_choff, r2, r2_stride, r2_choff,
                                          mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, body, tail, st);
-  if (tail > 0) {
-    p.tile_begin = body; p.ntiles = body + tail;
-    if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true, true>), dim3(2 * tail), dim3(512), SMEM_BYTES, st, p);
-    else hipLaunchKernelGGL((k_conv3x3_wino<false, true>), dim3(2 * tail), dim3(512), SMEM_BYTES, st, p);
-    LFSR_CHECK_LAUNCH();
-  }
   return LFSR_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_conv3x3.json from two rocprofv3 PMC passes of bench.py (FETCH_SIZE and WRITE_SIZE, csv output) and the
---kernel-trace --stats pass: HBM bytes per 3x3 conv op = body launch + channel-split tail launch of the Winograd kernel.
+--kernel-trace --stats pass: HBM bytes per 3x3 conv op (one launch of the Winograd kernel).
 usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <kernel_stats.csv> <out.json> [all_kernels.json]"""
 import csv, json, sys
 from collections import defaultdict
@@ -19,21 +19,21 @@ F, W = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
 pick = lambda d, key: next((v for k, v in d.items() if key in k), (0.0, 0))
 res = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1`; bytes = "
                  "(2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of "
-                 "16-B-per-lane coalesced reads at 64 B); mean over the launches of each kernel, summed over the two launches of one conv op "
+                 "16-B-per-lane coalesced reads at 64 B); mean over the launches of the kernel "
                  "(21 of 53 ops per forward also read a residual operand)"}
 total = 0.0
-for tag, key in (("body", "k_conv3x3_wino<false, false>"), ("tail", "k_conv3x3_wino<false, true>")):
+for tag, key in (("op", "k_conv3x3_wino<false>"),):
     f, n = pick(F, key); w, _ = pick(W, key)
     b = (2.0 * f + w) * 1024.0
     res[tag] = {"kernel": key, "launches": n, "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": b}
     total += b
-res["kernel"] = "k_conv3x3_wino<false,false> (body, 3072 tiles) + k_conv3x3_wino<false,true> (channel-split tail, 128 tiles): one 3x3 conv op"
+res["kernel"] = "k_conv3x3_wino<false>: one launch per 3x3 conv op (256 persistent body blocks over 3072 tiles + 256 channel-split blocks over the 128 leftover tiles)"
 res["hbm_bytes_per_launch"] = total
 n_pix = 32 * 25 * 32 * 32
 res["algorithmic_bytes_per_launch"] = n_pix * 256 * (2 + 21.0 / 53.0)   # in + out (+ residual on 21 of 53 ops)
 us = 0.0
 for r in csv.DictReader(open(stats)):
-    if "k_conv3x3_wino<false, false>" in r["Name"] or "k_conv3x3_wino<false, true>" in r["Name"]:
+    if "k_conv3x3_wino<false>" in r["Name"]:
         us += float(r["AverageNs"]) / 1000.0
 res["rocprof_avg_us_per_op"] = us
 json.dump(res, open(out, "w"), indent=1)
