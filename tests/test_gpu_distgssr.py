@@ -85,6 +85,30 @@ def test_conv3x3_tail_and_fallback_kernels(monkeypatch):
         assert np.abs(from_vcl(y, B, 64, A, h, w) - ref).max() < ATOL, env
 
 
+def test_conv3x3_bench_size_properties(monkeypatch):
+    """BASELINE geometry of the headline bench (800 view images of 32x32: 12 full rounds of 256 tiles + 128 leftover tiles), where
+    the fp64 oracle is too slow: the Winograd kernel must agree with the direct 9-tap kernel, and be linear in its input"""
+    n_img, h, w = 32 * 25, 32, 32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(n_img * h * w, 64, device="cuda", generator=g)
+    z = torch.randn(n_img * h * w, 64, device="cuda", generator=g)
+    r = torch.randn(n_img * h * w, 64, device="cuda", generator=g)
+    wp = capi.pack_conv_weight(torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05)
+    for k in ("LFSR_CONV_TAIL", "LFSR_CONV_NOTAIL", "LFSR_CONV3X3"):
+        monkeypatch.delenv(k, raising=False)
+    yw = capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=r)
+    monkeypatch.setenv("LFSR_CONV3X3", "halo")
+    yd = capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=r)
+    monkeypatch.delenv("LFSR_CONV3X3")
+    torch.cuda.synchronize()
+    assert float((yw - yd).abs().max()) < 2e-5                      # two fp32 evaluation orders of the same sums
+    # linearity (slope 1, no residual): conv(2 x - 3 z) == 2 conv(x) - 3 conv(z)
+    lin = capi.conv3x3(2.0 * x - 3.0 * z, wp, n_img, h, w, slope=1.0)
+    ref = 2.0 * capi.conv3x3(x, wp, n_img, h, w, slope=1.0) - 3.0 * capi.conv3x3(z, wp, n_img, h, w, slope=1.0)
+    torch.cuda.synchronize()
+    assert float((lin - ref).abs().max()) < 1e-4
+
+
 @pytest.mark.parametrize("B,A,h,w", GEOMS)
 def test_angconv(B, A, h, w):
     x = rnd((B, 64, A * h, A * w), 4)
