@@ -82,27 +82,36 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
 
   const int nvec = LINES * PP;                      // input vectors per stage
   float4 ra[9], rw[5];                              // A <= 5 fast path sizes (checked by the launcher)
+  // Stage loads through buffer descriptors: the per-thread byte offsets of its 9 input vectors and 5 weight rows are worked out
+  // ONCE per block (line bases from LDS, bounds -> out-of-range offsets that read as zero); a stage only adds the view's
+  // wave-uniform offset.  As per-stage branches with 64-bit addresses this code sat un-overlapped in front of every stage's MFMAs.
+  constexpr int EOOB = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, EOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W1), 0, A * A * 32 * 64 * 4, 0x00020000);
+  int offA[9], offW[5];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int vec = r16 + 32 * i, l = vec < nvec ? vec / PP : 0, t = vec - l * PP - pad;
+    const int base = sLine[l];
+    offA[i] = (vec < nvec && base >= 0 && t >= 0 && t < len) ? ((base + t * pstride) * p.x_stride + p.x_choff + c16 * 4) * 4 : EOOB;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int row = r16 + 32 * i, dxi = row >> 5, n = row & 31;   // (dxi, n)
+    offW[i] = row < A * 32 ? ((A * dxi * 32 + n) * 64 + c16 * 4) * 4 : EOOB;
+  }
+  typedef float f32x4e __attribute__((ext_vector_type(4)));
   auto prefetch = [&](int vv) {
+    const int sA4 = vv * vstride * p.x_stride * 4, sW4 = vv * 32 * 64 * 4;   // wave-uniform
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      int vec = r16 + 32 * i;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vec < nvec) {
-        int l = vec / PP, pp = vec - l * PP;
-        int t = pp - pad;
-        int base = sLine[l];
-        if (base >= 0 && t >= 0 && t < len)
-          ra[i] = *reinterpret_cast<const float4*>(p.X + ((long long)base + (long long)vv * vstride + (long long)t * pstride) * p.x_stride + p.x_choff + c16 * 4);
-      }
+      const f32x4e v = __builtin_bit_cast(f32x4e, __builtin_amdgcn_raw_buffer_load_b128(rsX, offA[i], sA4, 0));
+      ra[i] = make_float4(v.x, v.y, v.z, v.w);
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-      int row = r16 + 32 * i;                       // (dxi, n)
-      rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < A * 32) {
-        int dxi = row >> 5, n = row & 31;
-        rw[i] = *reinterpret_cast<const float4*>(p.W1 + ((long long)(A * dxi + vv) * 32 + n) * 64 + c16 * 4);
-      }
+      const f32x4e v = __builtin_bit_cast(f32x4e, __builtin_amdgcn_raw_buffer_load_b128(rsW, offW[i], sW4, 0));
+      rw[i] = make_float4(v.x, v.y, v.z, v.w);
     }
   };
 
@@ -220,6 +229,7 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
                           int choffH, int choffV, float* t_h, float* t_v, int B, int A, int h, int w, int which, float slope, hipStream_t st) {
   // which: 1 = horizontal only, 2 = vertical only, 3 = both
   if (!lfsr_epi_fused_ok(A, h, w)) return LFSR_E_ARG;
+  if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;

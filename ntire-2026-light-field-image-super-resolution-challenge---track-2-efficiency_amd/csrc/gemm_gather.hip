@@ -282,7 +282,7 @@ int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
                      float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical, float slope, void* stream) {
   if (!x || !w1_packed || !w2_packed || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < y_choff + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
-  if (epi_use_fused(A, h, w) && !((y_stride | y_choff) & 3))   // (16-B output vectors)
+  if (epi_use_fused(A, h, w) && !((y_stride | y_choff) & 3) && (long long)B * A * A * h * w * x_stride * 4 < (1LL << 31))   // (16-B output vectors, 32-bit offsets)
     return lfsr_epi_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, y, y_stride, y_choff, y_choff, nullptr, nullptr, B, A, h, w, vertical ? 2 : 1, slope, lfsr_stream(stream));
   if (!tmp) return LFSR_E_ARG;
   return lfsr_epiconv_gather(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, y_choff, B, A, h, w, vertical, slope, lfsr_stream(stream));
@@ -292,7 +292,7 @@ int lfsr_epiconv_hv_fwd(const float* x, int x_stride, int x_choff, const float* 
                         float* tmp, float* y, int y_stride, int choff_h, int choff_v, int B, int A, int h, int w, float slope, void* stream) {
   if (!x || !w1_packed || !w2_packed || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < choff_h + 32 || y_stride < choff_v + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
-  if (epi_use_fused(A, h, w) && !((y_stride | choff_h | choff_v) & 3))
+  if (epi_use_fused(A, h, w) && !((y_stride | choff_h | choff_v) & 3) && (long long)B * A * A * h * w * x_stride * 4 < (1LL << 31))
     return lfsr_epi_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, y, y_stride, choff_h, choff_v, nullptr, nullptr, B, A, h, w, 3, slope, lfsr_stream(stream));
   if (!tmp) return LFSR_E_ARG;
   int rc = lfsr_epiconv_gather(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, choff_h, B, A, h, w, 0, slope, lfsr_stream(stream));
