@@ -57,17 +57,24 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
     }
   }
 
+  // row-tile loads through a buffer descriptor sized to the tensor: a thread's AL byte offsets inside a tile are constants, the tile
+  // adds a wave-uniform offset, rows past M are out of range and read as zero -- no branches, no 64-bit address arithmetic between
+  // the barrier and the MFMAs (the launcher checks the tensor spans < 2 GiB)
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)(p.M * p.x_stride * 4), 0x00020000);
+  int offX[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int idx = tid + NTH * i, r = idx / CPR, c = idx - r * CPR;
+    offX[i] = idx < BMR * CPR ? (r * p.x_stride + p.x_choff + c * 4) * 4 : (int)0x80000000u;
+  }
   float4 ra[AL];
   auto prefetch = [&](long long tile) {
-    const long long m0 = tile * BMR;
+    const int s4 = (int)(tile * BMR) * p.x_stride * 4;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      int idx = tid + NTH * i;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < BMR * CPR) {
-        int r = idx / CPR, c = idx - r * CPR;
-        if (m0 + r < p.M) ra[i] = *reinterpret_cast<const float4*>(p.X + (m0 + r) * p.x_stride + p.x_choff + c * 4);
-      }
+      const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offX[i], s4, 0));
+      ra[i] = make_float4(v.x, v.y, v.z, v.w);
     }
   };
 
@@ -173,6 +180,7 @@ int launch_rowgemm(const RowGemmArgs& p, hipStream_t st) {
 int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
                         const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st) {
   if ((x_stride | x_choff) & 3 || N % 32) return LFSR_E_ARG;
+  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x (caller falls back to the gather-GEMM)
   RowGemmArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.bias = bias; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = slope;
