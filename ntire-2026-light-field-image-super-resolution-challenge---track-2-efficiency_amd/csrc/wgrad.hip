@@ -131,31 +131,35 @@ __global__ __launch_bounds__(512) void k_wgrad_conv3_halo(Wgrad3Args p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  // tile loads through buffer descriptors with 32-bit offsets (the launcher checks the spans): image borders and ragged edges
+  // are out-of-range offsets that read as zero instead of per-pixel branches with 64-bit addresses
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+  constexpr int WOOB = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, WOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, WOOB, 0x00020000);
   float4 hx[7], hg[4];
   auto load_tile = [&](int tile) {
     int tx = tile % p.tiles_x; int qq = tile / p.tiles_x;
     int ty = qq % p.tiles_y; int img = qq / p.tiles_y;
     const int y0 = ty * WT_R, x0 = tx * WT_C;
-    const long long ib = (long long)img * p.H * p.W;
+    const int ib = img * p.H * p.W;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      int pix = r16 + 32 * i;
-      hx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pix < WX_PIX) {
-        int r = pix / (WT_C + 2), c = pix - r * (WT_C + 2);
-        int yy = y0 + r - 1, xx = x0 + c - 1;
-        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
-          hx[i] = *reinterpret_cast<const float4*>(p.X + (ib + (long long)yy * p.W + xx) * p.x_stride + p.x_choff + c16 * 4);
-      }
+      const int pix = r16 + 32 * i;
+      const int r = pix / (WT_C + 2), c = pix - r * (WT_C + 2);
+      const int yy = y0 + r - 1, xx = x0 + c - 1;
+      const bool ok = pix < WX_PIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((ib + yy * p.W + xx) * p.x_stride + p.x_choff + c16 * 4) * 4 : WOOB, 0, 0));
+      hx[i] = make_float4(v.x, v.y, v.z, v.w);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int pix = r16 + 32 * i;
-      int r = pix / WT_C, c = pix - r * WT_C;
-      int yy = y0 + r, xx = x0 + c;
-      hg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (yy < p.H && xx < p.W)
-        hg[i] = *reinterpret_cast<const float4*>(p.G + (ib + (long long)yy * p.W + xx) * p.g_stride + p.g_choff + c16 * 4);
+      const int pix = r16 + 32 * i;
+      const int r = pix / WT_C, c = pix - r * WT_C;
+      const int yy = y0 + r, xx = x0 + c;
+      const bool ok = yy < p.H && xx < p.W;
+      const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? ((ib + yy * p.W + xx) * p.g_stride + p.g_choff + c16 * 4) * 4 : WOOB, 0, 0));
+      hg[i] = make_float4(v.x, v.y, v.z, v.w);
     }
   };
 
@@ -310,6 +314,7 @@ int lfsr_wgrad_conv3_blocks(int n_img, int h, int w) {
 int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P,
                             int n_img, int h, int w, hipStream_t st) {
   if (!G || !X || !P || n_img <= 0 || h <= 0 || w <= 0 || ((g_stride | g_choff | x_stride | x_choff) & 3)) return LFSR_E_ARG;
+  if ((long long)n_img * h * w * (x_stride > g_stride ? x_stride : g_stride) * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
