@@ -31,6 +31,7 @@ struct GemmArgs {
   float slope;                     // LeakyReLU slope; 1.0f = identity, 0.0f = ReLU
   int S;                           // OUT_PS_HR: upscale factor
   int nblk_m;                      // number of row blocks (for the XCD remap)
+  int addr32;                      // set by launch_gemm: the gathered tensor spans < 2 GiB -> descriptor loads with 32-bit offsets
 };
 
 constexpr int BM = 128;
@@ -146,16 +147,30 @@ __global__ __launch_bounds__(256) void k_gemm_gather(GemmArgs p) {
   float4 ra[AROWS], rb[BROWS];
   const int nstages = p.ntaps * NCH;
 
+  // stage loads: with 32-bit addressing (launch_gemm checks the span) through a buffer descriptor -- padding / out-of-range rows
+  // become out-of-range offsets that read as zero, no per-row branch and no 64-bit address arithmetic between the barrier and
+  // the MFMAs; the 64-bit form remains for larger tensors
+  typedef float f32x4q __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)0x80000000u, 0x00020000);
   auto prefetch = [&](int s) {
     const int tap = s / NCH, ch = s - tap * NCH;
     const int kw = (ch == NCH - 1) ? LASTW : 64;
     const int koff = ch * 64 + c16 * 4;
     const bool kin = c16 * 4 < kw;
+    if (p.addr32) {
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      int sp = src_pixel<IN>(rows[i], tap, p);
-      ra[i] = (sp >= 0 && kin) ? *reinterpret_cast<const float4*>(p.X + (long long)sp * p.x_stride + p.x_choff + koff)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < AROWS; ++i) {
+        const int sp = src_pixel<IN>(rows[i], tap, p);
+        const f32x4q v = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rsX, (sp >= 0 && kin) ? (sp * p.x_stride + p.x_choff + koff) * 4 : (int)0x80000000u, 0, 0));
+        ra[i] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        int sp = src_pixel<IN>(rows[i], tap, p);
+        ra[i] = (sp >= 0 && kin) ? *reinterpret_cast<const float4*>(p.X + (long long)sp * p.x_stride + p.x_choff + koff)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) {
@@ -249,6 +264,7 @@ int launch_gemm(GemmArgs p, hipStream_t st) {
   if (p.M <= 0) return LFSR_OK;
   if (p.Npad % (32 * NT) != 0 && NT != 1) return LFSR_E_ARG;
   p.nblk_m = (p.M + BM - 1) / BM;
+  p.addr32 = (long long)p.M * (p.AA > 0 ? p.AA : 1) * p.x_stride * 4 < (1LL << 31);   // every gather reads at most M * A^2 pixels
   dim3 grid((unsigned)p.nblk_m, (unsigned)((p.Npad + 32 * NT - 1) / (32 * NT)));
   hipLaunchKernelGGL((k_gemm_gather<IN, OUT, CIN, NT>), grid, dim3(256), 0, st, p);
   LFSR_CHECK_LAUNCH();
