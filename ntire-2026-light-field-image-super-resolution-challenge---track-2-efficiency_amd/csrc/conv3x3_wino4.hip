@@ -1,0 +1,332 @@
+// Per-view 3x3 conv, zero pad 1, 64 -> 64 channels, VCL layout -- Winograd F(4x4, 3x3) on the fp32 MFMA pipe.
+// Reference: the MacPI convs "k3, dilation A, padding A" of model/SR/DistgSSR.py:22,47,64,79-83,101 (per-view 3x3 in VCL),
+// EPIT.py:24-32,136-142 / LFT.py:36-46 (Conv3d(1,3,3)).
+//
+//   Y = At [ sum_c (G g G^t) . (Bt d B) ] A     per 4x4 output tile, d = its 6x6 input patch, 36 transform positions p = (xi, nu)
+//
+// 36 position-GEMMs per 16 outputs = 2.25 multiplies per output and channel pair instead of 9 (direct) or 4 (F(2x2,3x3)).
+// The transform coefficients are small integers (Bt: 1, 2, 4, 5; At: 1, 2, 4, 8) and 1/4, 1/6, 1/12, 1/24 in G, which is applied
+// in fp64 at pack time; round-off of the whole DistgSSR forward stays at 1e-6 (tools/conv_error.py).
+//
+// One 256-thread block = one 8-row x 32-column output tile = 16 Winograd tiles; TWO blocks per CU (75 KB of LDS, <= 256
+// registers each), so one block's epilogue and barrier waits lie under the other block's MFMAs.
+//  * roles.  Every thread is a producer of one (Winograd tile, channel) item per 16-channel chunk: 36 dword loads of its 6x6
+//    patch straight from global memory (16 consecutive lanes = 16 consecutive channels = 64 B runs; zero padding and ragged
+//    edges are out-of-range buffer offsets), the 2-D input transform in registers (144 FMAs), nine ds_write_b128 into the V
+//    buffer of the NEXT chunk.  Every wave is the consumer of one 16-channel slice ns of the OUTPUT channels for all 16 tiles:
+//    v_mfma_f32_16x16x4_f32 with A = U (rows = output channels) and B = V (columns = tiles), 36 accumulators of 4 registers,
+//    so the whole inverse transform At M A happens in registers -- no cross-wave exchange, no seam barriers.
+//  * V[parity][tile][channel 0..15][36 positions] in LDS, tile stride 584 floats: the 16-lane groups of ds_read_b128 and the
+//    8-lane groups of ds_write_b128 are both conflict-free.  One barrier per chunk (= per 144 MFMAs of a wave).
+//  * U never touches LDS: the pack is in fragment order [stage k/4][ns][p/4][lane][p%4], a wave streams its 9 KB per stage
+//    through a register ring of 16-B fragments (L2 hits, 1 KB contiguous per wave instruction).
+//  * epilogue from registers: lane = (tile, 4 consecutive output channels) -> 16-B stores / residual loads per pixel.
+#include <stdlib.h>
+
+#include "lfsr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef W4_ABL
+#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no patch loads, 2 no input transform, 4 no V writes, 8 no U loads, 16 no V reads, 32 no epilogue, 64 no chunk barrier
+#endif
+#ifndef W4_BPC
+#define W4_BPC 1      // blocks per CU: 2 (<= 256 registers per wave) or 1 (<= 512)
+#endif
+#ifndef W4_URING
+#define W4_URING 12   // depth of the U fragment ring (16-B fragments in flight per wave); must divide 144
+#endif
+
+namespace {
+
+constexpr int TS = 584;                 // floats per tile in a V buffer: 16 channels x 36 positions + 8 (2336 B = 32 mod 256)
+constexpr int VBUF = 16 * TS;           // one parity
+constexpr int SMEM_BYTES = 2 * VBUF * 4;   // 74752
+constexpr int INV = 1 << 30;            // "outside the image" marker of a row / column offset (operands span < 1 GiB)
+constexpr int OOB = (int)0x80000000u;
+
+struct Wino4Args {
+  const float* X; int x_stride; int x_choff; int x_bytes;
+  const float* Wu;   // [16 stages][4 ns][9 q][64 lanes][4]   (lfsr_pack_wino4)
+  float* Y; int y_stride; int y_choff;
+  const float* R1; int r1_stride; int r1_choff;
+  const float* R2; int r2_stride; int r2_choff;
+  const float* Mk; int mk_stride; int mk_choff; float mk_slope;
+  int n_img, H, W, tiles_y, tiles_x, ntiles;
+  float slope;
+};
+
+#define LDS_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+}
+
+// one 6-vector of the input transform: t = Bt d  (12 operations, integer coefficients: exact products)
+__device__ __forceinline__ void bt6(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {
+  const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+  const float c = d4 - d2, e = d3 - d1;
+  const float t0 = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+  const float t5 = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+  d0 = t0; d1 = a + b; d2 = a - b; d3 = fmaf(2.f, e, c); d4 = fmaf(-2.f, e, c); d5 = t5;
+}
+// one 6-vector of the output transform: y = At m  (4 results)
+__device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, const f32x4 m4, const f32x4 m5) {
+  const f32x4 s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+  m0 = (m0 + s12) + s34;
+  m1 = d12 + 2.f * d34;
+  m2 = s12 + 4.f * s34;
+  m3 = (d12 + 8.f * d34) + m5;
+}
+
+template <bool MASK>
+__global__ __launch_bounds__(256, W4_BPC) void k_conv3x3_wino4(Wino4Args p) {
+  extern __shared__ __attribute__((aligned(16))) float sV[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = gridDim.x;
+  // producer item: channel c16 of Winograd tile ptile = (pty, ptx); consumer fragment: tile ctile, channel 4 s + kk of a stage
+  const int c16 = lane & 15, ptile = 4 * wave + (lane >> 4), pty = ptile >> 3, ptx = ptile & 7;
+  const int ctile = lane & 15, kk = lane >> 4, cty = ctile >> 3, ctx = ctile & 7;
+  const int ns = wave;
+
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsW = make_rsrc(p.Wu, 36 * 64 * 64 * 4), rsY = make_rsrc(p.Y, OOB);
+  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, (MASK ? p.Mk : p.R1) ? OOB : 0);   // prefetched epilogue operand
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(MASK ? p.R1 : p.R2, (MASK ? p.R1 : p.R2) ? OOB : 0);   // late epilogue operand
+  const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
+  const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
+  const bool has_e = (MASK ? p.Mk : p.R1) != nullptr, has_l = (MASK ? p.R1 : p.R2) != nullptr;
+
+  auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
+    int txx = t % p.tiles_x; int q = t / p.tiles_x;
+    int tyy = q % p.tiles_y; img = q / p.tiles_y;
+    y0 = tyy * 8; x0 = txx * 32;
+  };
+  // byte offsets of the producer's 6 patch rows and 6 patch columns (sum = element offset; INV in either -> out of range)
+  int ro[6], co[6];
+  auto patch_offsets = [&](bool valid, int img, int y0, int x0) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int yy = y0 + 4 * pty - 1 + r;
+      ro[r] = (valid && (unsigned)yy < (unsigned)p.H) ? ((img * p.H + yy) * p.W) * (p.x_stride * 4) : INV;
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int xx = x0 + 4 * ptx - 1 + c;
+      co[c] = ((unsigned)xx < (unsigned)p.W) ? xx * (p.x_stride * 4) + (p.x_choff + c16) * 4 : INV;
+    }
+  };
+  float raw[36];
+  auto load_raw = [&](int chunk) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(ro[r]));   // the 36 sums are formed here, not kept across the tile
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) raw[6 * r + c] = bload1(rsX, ro[r] + co[c], chunk * 64);
+  };
+  auto transform_cols = [&]() {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) bt6(raw[c], raw[6 + c], raw[12 + c], raw[18 + c], raw[24 + c], raw[30 + c]);
+  };
+  auto transform_rows = [&]() {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) bt6(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2], raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5]);
+  };
+  float* const vW = sV + ptile * TS + c16 * 36;          // producer's 36 floats (parity 0)
+  const float* const vR = sV + ctile * TS + kk * 36;     // consumer's fragment base (parity 0, stage 0): + s4 * 144 + 4 q
+  auto write_v = [&](int par) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      f32x4 v; v.x = raw[4 * q]; v.y = raw[4 * q + 1]; v.z = raw[4 * q + 2]; v.w = raw[4 * q + 3];
+      *reinterpret_cast<f32x4*>(vW + par * VBUF + 4 * q) = v;
+    }
+  };
+  const int uoff = ns * 9216 + lane * 16;   // byte offset of this lane's U fragments within a stage (q = 0)
+
+  int tile = blockIdx.x;
+  int img, y0, x0;
+  tile_origin(tile, img, y0, x0);
+
+  // ---- prologue: V of chunk 0 in buffer 0, U ring filled ----------------------------------------------------------------------
+  patch_offsets(true, img, y0, x0);
+  load_raw(0);
+  transform_cols(); transform_rows();
+  write_v(0);
+  f32x4 U[W4_URING];
+#pragma unroll
+  for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, uoff, ((i / 9) * 36 + (i % 9)) * 1024);
+  LDS_BARRIER();
+
+  f32x4 acc[36];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  while (true) {
+    const int next = tile + nblk;
+    const bool has_next = next < p.ntiles;
+    int nimg = 0, ny0 = 0, nx0 = 0;
+    if (has_next) tile_origin(next, nimg, ny0, nx0);
+
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int par = c & 1;
+      // consumer: 4 stages x 9 fragment groups x 4 MFMAs.  Producer, in the same chunk: the patch of chunk c + 1 (chunk 0 of the
+      // next tile when c == 3) is requested during stage 0, transformed during stages 2 and 3 and written to the other V buffer
+      // before the barrier -- the patch registers are dead at the barrier, hence during the epilogue
+      f32x4 Vq[2];
+      Vq[0] = *reinterpret_cast<const f32x4*>(vR + par * VBUF);
+      if (W4_ABL & 16) Vq[1] = Vq[0];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (s4 == 0) {
+          if (c == 3) patch_offsets(has_next, nimg, ny0, nx0);
+          if (!(W4_ABL & 1)) load_raw((c + 1) & 3);
+        }
+        if (s4 == 2 && !(W4_ABL & 2)) transform_cols();
+        if (s4 == 3) { if (!(W4_ABL & 2)) transform_rows(); if (!(W4_ABL & 4)) write_v(par ^ 1); }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int t = (c * 4 + s4) * 9 + q;      // fragment group of the tile, 0..143
+          const int g = s4 * 9 + q;                // ... of the chunk
+          if (g + 1 < 36 && !(W4_ABL & 16)) Vq[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + ((g + 1) / 9) * 144 + ((g + 1) % 9) * 4);
+          const f32x4 u = U[t % W4_URING], v = Vq[g & 1];
+          const bool first = (c == 0 && s4 == 0);
+          acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v.x, first ? zero4 : acc[4 * q + 0], 0, 0, 0);
+          acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v.y, first ? zero4 : acc[4 * q + 1], 0, 0, 0);
+          acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[4 * q + 2], 0, 0, 0);
+          acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[4 * q + 3], 0, 0, 0);
+          const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
+          if (!(W4_ABL & 8)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(W4_ABL & 64)) LDS_BARRIER();   // V of the next chunk published; everyone is done reading this chunk's
+    }
+
+    // ---- epilogue: At M A in registers, then LeakyReLU / mask / residuals, 16 B per lane and pixel ---------------------------
+    if (W4_ABL & 32) {
+      f32x4 sum = acc[0];
+#pragma unroll
+      for (int i = 1; i < 36; ++i) sum += acc[i];
+      bstore4(rsY, ((img * p.H + y0 + 4 * cty) * p.W + x0 + 4 * ctx) * (p.y_stride * 4) + (16 * ns + 4 * kk) * 4, sum);
+    } else {
+      const int ybase = y0 + 4 * cty, xbase = x0 + 4 * ctx;
+      const int chq = (16 * ns + 4 * kk) * 4;   // byte offset of the lane's 4 channels within a 64-channel vector
+      auto pix_off = [&](int a, int b, int stride, int choff) -> int {
+        const int yy = ybase + a, xx = xbase + b;
+        return (yy < p.H && xx < p.W) ? ((img * p.H + yy) * p.W + xx) * (stride * 4) + choff * 4 + chq : OOB;
+      };
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) at6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        f32x4 res[4];
+        if (has_e) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) res[b] = bload4(rsE, pix_off(a, b, e_stride, e_choff), 0);
+        }
+        at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          f32x4 v = acc[6 * a + b];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * p.slope;
+          if (MASK) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= res[b][i] > 0.f ? 1.f : p.mk_slope;
+          } else if (has_e) {
+            v += res[b];
+          }
+          if (has_l) v += bload4(rsL, pix_off(a, b, l_stride, l_choff), 0);
+          bstore4(rsY, pix_off(a, b, p.y_stride, p.y_choff), v);
+        }
+      }
+    }
+    if (!has_next) break;
+    tile = next; img = nimg; y0 = ny0; x0 = nx0;
+  }
+}
+
+// U = G g G^t per (n, k) from the direct pack [tap][n][k] -> [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4]
+__global__ __launch_bounds__(256) void k_pack_wino4(const float* __restrict__ direct, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (n, k)
+  if (i >= 64 * 64) return;
+  const int n = i >> 6, k = i & 63;
+  double g[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)direct[(t * 64 + n) * 64 + k];
+  const double G[6][3] = {{1.0 / 4, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  double tmp[6][3];
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tmp[a][c] = G[a][0] * g[0][c] + G[a][1] * g[1][c] + G[a][2] * g[2][c];
+  const int s = k >> 2, kq = k & 3, nsl = n >> 4, m = n & 15;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
+      const int pp = a * 6 + b;
+      out[((((s * 4 + nsl) * 9 + (pp >> 2)) * 64 + kq * 16 + m) << 2) + (pp & 3)] = (float)u;
+    }
+}
+
+}  // namespace
+
+int lfsr_pack_wino4(const float* direct_packed, float* out, hipStream_t st) {
+  if (!direct_packed || !out) return LFSR_E_ARG;
+  hipLaunchKernelGGL(k_pack_wino4, dim3(16), dim3(256), 0, st, direct_packed, out);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+// LFSR_E_ARG = geometry not covered (operands of 1 GiB and more): the caller falls back to the F(2x2,3x3) kernel
+int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const float* w_wino4, float* y, int y_stride, int y_choff,
+                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                              int n_img, int h, int w, float slope, hipStream_t st) {
+  static bool attr_set[64] = {};
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    attr_set[dev] = true;
+  }
+  int ms = x_stride > y_stride ? x_stride : y_stride;
+  if (r1 && r1_stride > ms) ms = r1_stride;
+  if (r2 && r2_stride > ms) ms = r2_stride;
+  if (mk && mk_stride > ms) ms = mk_stride;
+  if ((long long)n_img * h * w * ms * 4 >= (1LL << 30)) return LFSR_E_ARG;
+  Wino4Args p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.x_bytes = (int)((long long)n_img * h * w * x_stride * 4);
+  p.Wu = w_wino4;
+  p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
+  p.R1 = r1; p.r1_stride = r1_stride; p.r1_choff = r1_choff; p.R2 = r2; p.r2_stride = r2_stride; p.r2_choff = r2_choff;
+  p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
+  p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + 7) / 8; p.tiles_x = (w + 31) / 32; p.slope = slope;
+  const long long nt = (long long)n_img * p.tiles_y * p.tiles_x;
+  if (nt <= 0 || nt > 0x7fffffffLL) return LFSR_E_ARG;
+  p.ntiles = (int)nt;
+  const int slots = W4_BPC * cus[dev];
+  const unsigned grid = (unsigned)(nt < slots ? nt : slots);
+  if (mk) hipLaunchKernelGGL((k_conv3x3_wino4<true>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((k_conv3x3_wino4<false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

@@ -592,6 +592,44 @@ def conv3x3_winograd(x, w):
     return y
 
 
+# F(4x4,3x3): the form the default HIP 3x3 kernel runs (conv3x3_wino4.hip); interpolation points 0, +-1, +-2, inf
+WINO4_BT = np.array([[4.0, 0.0, -5.0, 0.0, 1.0, 0.0], [0.0, -4.0, -4.0, 1.0, 1.0, 0.0], [0.0, 4.0, -4.0, -1.0, 1.0, 0.0],
+                     [0.0, -2.0, -1.0, 2.0, 1.0, 0.0], [0.0, 2.0, -1.0, -2.0, 1.0, 0.0], [0.0, 4.0, 0.0, -5.0, 0.0, 1.0]])
+WINO4_G = np.array([[1 / 4, 0.0, 0.0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6],
+                    [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0.0, 0.0, 1.0]])
+WINO4_AT = np.array([[1.0, 1.0, 1.0, 1.0, 1.0, 0.0], [0.0, 1.0, -1.0, 2.0, -2.0, 0.0],
+                     [0.0, 1.0, 1.0, 4.0, 4.0, 0.0], [0.0, 1.0, -1.0, 8.0, -8.0, 1.0]])
+
+
+def winograd4_weights(w):
+    """(O, C, 3, 3) -> U[6, 6, O, C] = G g Gt per (o, c), in the dtype of w"""
+    return np.einsum("ai,ocij,bj->aboc", WINO4_G.astype(w.dtype), w, WINO4_G.astype(w.dtype))
+
+
+def winograd4_pack(w):
+    """the device layout of the F(4x4,3x3) part of lfsr_pack_conv_weight for a (64, 64, 3, 3) weight:
+    [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4], p = 6 xi + nu (fp64 compute, one rounding to fp32)"""
+    U = winograd4_weights(w.astype(np.float64)).reshape(9, 4, 4, 16, 16, 4)   # q, e, ns, m, s, kq
+    return np.ascontiguousarray(U.transpose(4, 2, 0, 5, 3, 1)).astype(np.float32).reshape(-1)
+
+
+def conv3x3_winograd4(x, w):
+    """per-image 3x3 correlation, zero pad 1, via F(4x4,3x3): x (N, C, H, W) with H, W multiples of 4; w (O, C, 3, 3)"""
+    N, C, H, W = x.shape
+    assert H % 4 == 0 and W % 4 == 0
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    U = winograd4_weights(w)
+    y = np.zeros((N, w.shape[0], H, W), dtype=x.dtype)
+    BT, AT = WINO4_BT.astype(x.dtype), WINO4_AT.astype(x.dtype)
+    for ty in range(H // 4):
+        for tx in range(W // 4):
+            d = xp[:, :, 4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6]
+            V = np.einsum("ai,ncij,bj->abnc", BT, d, BT)
+            M = np.einsum("aboc,abnc->abno", U, V)
+            y[:, :, 4 * ty:4 * ty + 4, 4 * tx:4 * tx + 4] = np.einsum("ia,abno,jb->noij", AT, M, AT)
+    return y
+
+
 # ---- N4 output tail (utils/utils.py:191-204 ycbcr2rgb; train.py:329-341) ------------------------------------------------------
 def ycbcr2rgb(x):
     """(H, W, 3) YCbCr in [0, 1] -> RGB (float64): the reference's formula, operation for operation"""

@@ -164,3 +164,20 @@ def test_winograd_restatement_equals_direct_conv():
     U = O.winograd_weights(w64.astype(np.float64)).reshape(16, 64, 64)
     for (j, nt, p, hf, n32, e) in [(0, 0, 0, 0, 0, 0), (7, 1, 15, 1, 31, 3), (3, 0, 6, 1, 17, 2), (5, 1, 9, 0, 4, 1)]:
         assert pk[j, nt, p, hf, n32, e] == np.float32(U[p, 32 * nt + n32, 8 * j + 4 * hf + e])
+
+
+def test_winograd4_restatement_equals_direct_conv():
+    """the F(4x4,3x3) algebra of the default HIP conv kernel (oracle.conv3x3_winograd4) is the same correlation as conv2d"""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, 8, 8, 12))
+    w = rng.standard_normal((4, 8, 3, 3))
+    ref = O.conv2d(x, w, padding=(1, 1))
+    assert np.abs(O.conv3x3_winograd4(x, w) - ref).max() < 1e-11
+    y32 = O.conv3x3_winograd4(x.astype(np.float32), w.astype(np.float32))
+    assert np.abs(y32 - ref).max() < 2e-4          # fp32 round-off of F(4x4,3x3) on unit-variance data (|y| ~ 8)
+    # packed layout: entry (s, ns, q, lane, e) holds U[p = 4 q + e][n = 16 ns + lane % 16][k = 4 s + lane / 16]
+    w64 = rng.standard_normal((64, 64, 3, 3)).astype(np.float32)
+    pk = O.winograd4_pack(w64).reshape(16, 4, 9, 64, 4)
+    U = O.winograd4_weights(w64.astype(np.float64)).reshape(36, 64, 64)
+    for (s_, ns, q, ln, e) in [(0, 0, 0, 0, 0), (15, 3, 8, 63, 3), (3, 1, 5, 37, 2), (9, 2, 7, 16, 1)]:
+        assert pk[s_, ns, q, ln, e] == np.float32(U[4 * q + e, 16 * ns + ln % 16, 4 * s_ + ln // 16])
