@@ -29,20 +29,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W4_ABL
-#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no patch loads, 2 no input transform, 4 no V writes, 8 no U loads, 16 no V reads, 32 no epilogue, 64 no chunk barrier
+#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no halo loads, 2 no halo stores, 4 no V writes, 8 no patch reads / input transform, 16 no U loads, 32 no epilogue stores, 64 no second-operand loads, 128 no first-operand loads
 #endif
 #ifndef W4_BPC
 #define W4_BPC 1      // blocks per CU: 2 (<= 256 registers per wave) or 1 (<= 512)
 #endif
+#ifndef W4_SCHED
+#define W4_SCHED 4    // VALU instructions dealt out per MFMA gap (0: leave the stage to the compiler's scheduler)
+#endif
 #ifndef W4_URING
 #define W4_URING 12   // depth of the U fragment ring (16-B fragments in flight per wave); must divide 144
+#endif
+
+#ifdef LFSR_CONV_DIAG
+// diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
+#define STAMP(k) do { if (wave == 0) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
 #endif
 
 namespace {
 
 constexpr int TS = 584;                 // floats per tile in a V buffer: 16 channels x 36 positions + 8 (2336 B = 32 mod 256)
 constexpr int VBUF = 16 * TS;           // one parity
-constexpr int SMEM_BYTES = 2 * VBUF * 4;   // 74752
+constexpr int HPIX = 10 * 34;           // raw halo of an 8 x 32 tile
+constexpr int HPS = 20;                 // floats per halo pixel in LDS (16 channels of the chunk + 4: adjacent tiles 16 banks apart)
+constexpr int HBUF = HPIX * HPS;        // one parity
+constexpr int SMEM_BYTES = (2 * VBUF + 2 * HBUF + 256 + 2 * 4096) * 4;   // 162944: V, halo, 1 KB landing zone for the unused halo slots, epilogue exchange
 constexpr int INV = 1 << 30;            // "outside the image" marker of a row / column offset (operands span < 1 GiB)
 constexpr int OOB = (int)0x80000000u;
 
@@ -89,9 +102,15 @@ __device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, 
   m3 = (d12 + 8.f * d34) + m5;
 }
 
-template <bool MASK>
-__global__ __launch_bounds__(256, W4_BPC) void k_conv3x3_wino4(Wino4Args p) {
-  extern __shared__ __attribute__((aligned(16))) float sV[];
+// HAS_E / HAS_L: the first (residual R1, or the saved activation of the LeakyReLU' mask) / second epilogue operand exists.  An absent
+// operand must not even be requested: vector memory operations retire in order, a load queued behind the previous round's stores
+// waits for them
+template <bool MASK, bool HAS_E, bool HAS_L>
+__global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(Wino4Args p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const sV = smem;                               // V[2][16 tiles][16 ch][36]
+  float* const sH = smem + 2 * VBUF;                    // raw halo of one 16-channel chunk: [2][340 pixels][20] (16 used)
+  float* const sX = smem + 2 * VBUF + 2 * HBUF + 256;   // epilogue exchange: [2][64 pixels][64 channels]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nblk = gridDim.x;
   // producer item: channel c16 of Winograd tile ptile = (pty, ptx); consumer fragment: tile ctile, channel 4 s + kk of a stage
@@ -99,40 +118,61 @@ __global__ __launch_bounds__(256, W4_BPC) void k_conv3x3_wino4(Wino4Args p) {
   const int ctile = lane & 15, kk = lane >> 4, cty = ctile >> 3, ctx = ctile & 7;
   const int ns = wave;
 
-  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsW = make_rsrc(p.Wu, 36 * 64 * 64 * 4), rsY = make_rsrc(p.Y, OOB);
-  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, (MASK ? p.Mk : p.R1) ? OOB : 0);   // prefetched epilogue operand
-  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(MASK ? p.R1 : p.R2, (MASK ? p.R1 : p.R2) ? OOB : 0);   // late epilogue operand
+#ifdef LFSR_CONV_DIAG
+  long long seg[32] = {};
+  long long tprev = clock64();
+  float* dbgbuf = const_cast<float*>(p.R2);
+  p.R2 = nullptr;
+#endif
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, OOB), rsW = make_rsrc(p.Wu, 36 * 64 * 64 * 4), rsY = make_rsrc(p.Y, OOB);
+  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, (MASK ? p.Mk : p.R1) ? OOB : 0);   // first epilogue operand
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(MASK ? p.R1 : p.R2, (MASK ? p.R1 : p.R2) ? OOB : 0);   // second epilogue operand
   const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
   const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
-  const bool has_e = (MASK ? p.Mk : p.R1) != nullptr, has_l = (MASK ? p.R1 : p.R2) != nullptr;
 
+  // a block walks a CONTIGUOUS range of tiles: the next tile's halo shares two pixel rows (and its pages) with this one's
+  int tile = (int)(((long long)blockIdx.x * p.ntiles) / nblk);
+  const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.ntiles) / nblk);
   auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
     int txx = t % p.tiles_x; int q = t / p.tiles_x;
     int tyy = q % p.tiles_y; img = q / p.tiles_y;
     y0 = tyy * 8; x0 = txx * 32;
   };
-  // byte offsets of the producer's 6 patch rows and 6 patch columns (sum = element offset; INV in either -> out of range)
-  int ro[6], co[6];
-  auto patch_offsets = [&](bool valid, int img, int y0, int x0) {
+  // ---- halo staging: slot i of a thread = (halo pixel, 16-B quarter of the chunk's 64 B) = (idx >> 2, idx & 3), idx = tid + 256 i
+  int hx[6];   // global byte offsets (chunk 0) of the tile whose halo is being fetched; OOB outside the image
+  auto halo_offsets = [&](bool valid, int img, int y0, int x0) {
+    const int base = (((img * p.H + y0 - 1) * p.W + x0 - 1) * p.x_stride + p.x_choff) * 4;   // wave-uniform
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      const int yy = y0 + 4 * pty - 1 + r;
-      ro[r] = (valid && (unsigned)yy < (unsigned)p.H) ? ((img * p.H + yy) * p.W) * (p.x_stride * 4) : INV;
-    }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const int xx = x0 + 4 * ptx - 1 + c;
-      co[c] = ((unsigned)xx < (unsigned)p.W) ? xx * (p.x_stride * 4) + (p.x_choff + c16) * 4 : INV;
+    for (int i = 0; i < 6; ++i) {
+      const int px = (tid + 256 * i) >> 2, cq = tid & 3;
+      const int r = __mul24(px, 1928) >> 16;   // px / 34 for px < 384
+      const int c = px - r * 34;
+      const int yy = y0 + r - 1, xx = x0 + c - 1;
+      const bool ok = valid && px < HPIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      hx[i] = ok ? base + __mul24(__mul24(r, p.W) + c, p.x_stride * 4) + cq * 16 : OOB;
     }
   };
-  float raw[36];
-  auto load_raw = [&](int chunk) {
+  f32x4 hv[6];
+  auto halo_load = [&](int chunk) {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(ro[r]));   // the 36 sums are formed here, not kept across the tile
+    for (int i = 0; i < 6; ++i) hv[i] = bload4(rsX, hx[i], chunk * 64);
+  };
+  auto halo_store = [&](int par, int i0, int i1) {
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      const int px = (tid + 256 * i) >> 2, cq = tid & 3;
+      float* dst = (i < 5 || px < HPIX) ? sH + par * HBUF + px * HPS + cq * 4 : smem + 2 * VBUF + 2 * HBUF + (tid & 63) * 4;   // slots 340..383: landing zone
+      *reinterpret_cast<f32x4*>(dst) = hv[i];
+    }
+  };
+  // ---- producer: 6x6 patch of (ptile, c16) from the staged halo, Bt d B in registers, 36 values into V -----------------------
+  const float* const hR = sH + ((4 * pty) * 34 + 4 * ptx) * HPS + c16;
+  float raw[36];
+  auto read_raw = [&](int par) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) raw[6 * r + c] = bload1(rsX, ro[r] + co[c], chunk * 64);
+      for (int c = 0; c < 6; ++c) raw[6 * r + c] = hR[par * HBUF + (r * 34 + c) * HPS];
   };
   auto transform_cols = [&]() {
 #pragma unroll
@@ -144,116 +184,180 @@ __global__ __launch_bounds__(256, W4_BPC) void k_conv3x3_wino4(Wino4Args p) {
   };
   float* const vW = sV + ptile * TS + c16 * 36;          // producer's 36 floats (parity 0)
   const float* const vR = sV + ctile * TS + kk * 36;     // consumer's fragment base (parity 0, stage 0): + s4 * 144 + 4 q
-  auto write_v = [&](int par) {
+  auto write_v = [&](int par, int q0, int q1) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) {
+    for (int q = q0; q < q1; ++q) {
       f32x4 v; v.x = raw[4 * q]; v.y = raw[4 * q + 1]; v.z = raw[4 * q + 2]; v.w = raw[4 * q + 3];
       *reinterpret_cast<f32x4*>(vW + par * VBUF + 4 * q) = v;
     }
   };
   const int uoff = ns * 9216 + lane * 16;   // byte offset of this lane's U fragments within a stage (q = 0)
 
-  int tile = blockIdx.x;
   int img, y0, x0;
   tile_origin(tile, img, y0, x0);
 
-  // ---- prologue: V of chunk 0 in buffer 0, U ring filled ----------------------------------------------------------------------
-  patch_offsets(true, img, y0, x0);
-  load_raw(0);
-  transform_cols(); transform_rows();
-  write_v(0);
+  // ---- prologue: halo chunks 0 and 1 staged, chunk 2 in flight, V of chunk 0 in buffer 0, U ring filled ------------------------
+  halo_offsets(true, img, y0, x0);
+  halo_load(0); halo_store(0, 0, 6);
+  halo_load(1); halo_store(1, 0, 6);
+  halo_load(2);
   f32x4 U[W4_URING];
 #pragma unroll
   for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, uoff, ((i / 9) * 36 + (i % 9)) * 1024);
   LDS_BARRIER();
+  read_raw(0); transform_cols(); transform_rows(); write_v(0, 0, 9);
+  LDS_BARRIER();
 
-  f32x4 acc[36];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[36];
 
+  // ---- epilogue of one tile (img, y0, x0): At M A in registers, then -- one output row a of every Winograd tile per round -- the
+  // 64 pixels x 64 channels of the round go through LDS so that every global access is 16 B per lane, 256 B contiguous per pixel
+  // (straight from the accumulator layout a store instruction would touch sixteen separate 64-B pieces: measured 4x slower)
+  const int xw = (cty * 32 + 4 * ctx) * 64 + (((4 * ns + kk) ^ ctx) << 2);   // writer: pixel (row cty, col 4 ctx + b), 16-B unit XOR ctx
+  // reader slots of a round: (pixel, unit) = (idx >> 4, idx & 15), idx = tid + 256 i
+  auto reader_pix = [&](int a, int i, int eimg, int ey0, int ex0) -> int {
+    const int px = (tid + 256 * i) >> 4;
+    const int yy = ey0 + 4 * (px >> 5) + a, xx = ex0 + (px & 31);
+    return (yy < p.H && xx < p.W) ? (eimg * p.H + yy) * p.W + xx : -1;
+  };
+  f32x4 eop[HAS_E ? 8 : 1];   // rounds a and a + 1
+  // first-operand loads k = 4 a + i of rounds a = k / 4 (slots eop[k % 8]): rounds 0 and 1 are requested during the last stage of the
+  // K loop, round a + 2 between the arithmetic and the stores of round a -- never behind a store of its own tile
+  auto epilogue_request = [&](int eimg, int ey0, int ex0, int k0, int k1) {
+    if (HAS_E) {
+#pragma unroll
+      for (int k = k0; k < k1; ++k) {
+        const int pix = reader_pix(k >> 2, k & 3, eimg, ey0, ex0);
+        eop[HAS_E ? k & 7 : 0] = bload4(rsE, pix >= 0 ? pix * (e_stride * 4) + e_choff * 4 + (tid & 15) * 16 : OOB, 0);
+      }
+    }
+  };
+  auto epilogue = [&](int eimg, int ey0, int ex0) {
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) at6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float* const xb = sX + (a & 1) * 4096;
+      at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(xb + xw + b * 64) = acc[6 * a + b];
+      LDS_BARRIER();
+      f32x4 vo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int px = (tid + 256 * i) >> 4, un = tid & 15;
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + px * 64 + ((un ^ ((px >> 2) & 7)) << 2));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+        if (MASK) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] *= eop[HAS_E ? 4 * (a & 1) + i : 0][k] > 0.f ? 1.f : p.mk_slope;
+        } else if (HAS_E) {
+          v += eop[HAS_E ? 4 * (a & 1) + i : 0];
+        }
+        vo[i] = v;
+      }
+      if (a < 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue_request(eimg, ey0, ex0, 4 * (a + 2), 4 * (a + 2) + 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int un = tid & 15;
+        const int pix = reader_pix(a, i, eimg, ey0, ex0);
+        f32x4 v = vo[i];
+        if (HAS_L) v += bload4(rsL, pix >= 0 ? pix * (l_stride * 4) + l_choff * 4 + un * 16 : OOB, 0);   // (rare: waits for the stores ahead of it)
+        bstore4(rsY, pix >= 0 ? pix * (p.y_stride * 4) + p.y_choff * 4 + un * 16 : OOB, v);
+      }
+    }
+  };
+
+  // One tile = 4 chunks x 4 stages x 9 fragment groups x 4 MFMAs.  In the same instruction stream, per chunk g (parity par):
+  //   stage 0: patch of chunk g + 1 from the staged halo;   stage 1: column transform, first half of the halo of chunk g + 2 (in
+  //   registers since the previous chunk) -> LDS;   stages 2, 3: row transform and V of chunk g + 1 -> the other V buffer, half each;
+  //   second half of the halo -> LDS (2), request the halo of chunk g + 3 (3);   barrier.
   while (true) {
-    const int next = tile + nblk;
-    const bool has_next = next < p.ntiles;
+    const int next = tile + 1;
+    const bool has_next = next < tile_end;
     int nimg = 0, ny0 = 0, nx0 = 0;
     if (has_next) tile_origin(next, nimg, ny0, nx0);
-
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int par = c & 1;
-      // consumer: 4 stages x 9 fragment groups x 4 MFMAs.  Producer, in the same chunk: the patch of chunk c + 1 (chunk 0 of the
-      // next tile when c == 3) is requested during stage 0, transformed during stages 2 and 3 and written to the other V buffer
-      // before the barrier -- the patch registers are dead at the barrier, hence during the epilogue
-      f32x4 Vq[2];
+      f32x4 Vq[3];
       Vq[0] = *reinterpret_cast<const f32x4*>(vR + par * VBUF);
-      if (W4_ABL & 16) Vq[1] = Vq[0];
+      Vq[1] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + 4);
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        if (s4 == 0) {
-          if (c == 3) patch_offsets(has_next, nimg, ny0, nx0);
-          if (!(W4_ABL & 1)) load_raw((c + 1) & 3);
-        }
-        if (s4 == 2 && !(W4_ABL & 2)) transform_cols();
-        if (s4 == 3) { if (!(W4_ABL & 2)) transform_rows(); if (!(W4_ABL & 4)) write_v(par ^ 1); }
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
           const int t = (c * 4 + s4) * 9 + q;      // fragment group of the tile, 0..143
           const int g = s4 * 9 + q;                // ... of the chunk
-          if (g + 1 < 36 && !(W4_ABL & 16)) Vq[(g + 1) & 1] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + ((g + 1) / 9) * 144 + ((g + 1) % 9) * 4);
-          const f32x4 u = U[t % W4_URING], v = Vq[g & 1];
+          if (g + 2 < 36) Vq[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + ((g + 2) / 9) * 144 + ((g + 2) % 9) * 4);
+          // -- this group's slice of the producer work (the scheduler may not move anything across a group: one wave per SIMD,
+          //    nobody else fills an MFMA gap, and an LDS read parked right in front of its use exposes the whole LDS latency)
+          if (s4 == 0 && !(W4_ABL & 8)) {
+#pragma unroll
+            for (int e = 4 * q; e < 4 * q + 4; ++e) raw[e] = hR[(par ^ 1) * HBUF + ((e / 6) * 34 + e % 6) * HPS];
+          }
+          if (s4 == 1) {
+            if (q < 6 && !(W4_ABL & 8)) bt6(raw[q], raw[6 + q], raw[12 + q], raw[18 + q], raw[24 + q], raw[30 + q]);
+            if (q >= 6 && !(W4_ABL & 2)) halo_store(par, q - 6, q - 5);
+          }
+          if (s4 == 2 && !(W4_ABL & 8)) {
+            if (q < 6) bt6(raw[6 * q], raw[6 * q + 1], raw[6 * q + 2], raw[6 * q + 3], raw[6 * q + 4], raw[6 * q + 5]);
+            if (!(W4_ABL & 4)) {   // fragment j needs rows <= (4 j + 3) / 6: one write per group, a group behind its last row
+              if (q >= 1 && q <= 5) write_v(par ^ 1, q - 1, q);
+              if (q == 6) write_v(par ^ 1, 5, 7);
+              if (q == 7) write_v(par ^ 1, 7, 8);
+              if (q == 8) write_v(par ^ 1, 8, 9);
+            }
+          }
+          if (s4 == 3) {
+            if (q < 3 && !(W4_ABL & 2)) halo_store(par, 3 + q, 4 + q);
+            if (q == 2 && c == 1) halo_offsets(has_next, nimg, ny0, nx0);   // chunk g + 3 is chunk 0 of the next tile from here on
+            if (q >= 3 && !(W4_ABL & 1)) hv[q - 3] = bload4(rsX, hx[q - 3], ((c + 3) & 3) * 64);
+            if (c == 3 && q < 8) epilogue_request(img, y0, x0, q, q + 1);
+          }
+          // -- consumer
+          const f32x4 u = U[t % W4_URING], v = Vq[g % 3];
           const bool first = (c == 0 && s4 == 0);
           acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v.x, first ? zero4 : acc[4 * q + 0], 0, 0, 0);
           acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v.y, first ? zero4 : acc[4 * q + 1], 0, 0, 0);
           acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[4 * q + 2], 0, 0, 0);
           acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[4 * q + 3], 0, 0, 0);
           const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
-          if (!(W4_ABL & 8)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (!(W4_ABL & 64)) LDS_BARRIER();   // V of the next chunk published; everyone is done reading this chunk's
-    }
-
-    // ---- epilogue: At M A in registers, then LeakyReLU / mask / residuals, 16 B per lane and pixel ---------------------------
-    if (W4_ABL & 32) {
-      f32x4 sum = acc[0];
+          if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
+          // a 16x16x4 fp32 MFMA holds the matrix pipe for 32 cycles and the wave's issue slot for 4-8: the group's other
+          // instructions go between its four MFMAs
+#if W4_SCHED
 #pragma unroll
-      for (int i = 1; i < 36; ++i) sum += acc[i];
-      bstore4(rsY, ((img * p.H + y0 + 4 * cty) * p.W + x0 + 4 * ctx) * (p.y_stride * 4) + (16 * ns + 4 * kk) * 4, sum);
-    } else {
-      const int ybase = y0 + 4 * cty, xbase = x0 + 4 * ctx;
-      const int chq = (16 * ns + 4 * kk) * 4;   // byte offset of the lane's 4 channels within a 64-channel vector
-      auto pix_off = [&](int a, int b, int stride, int choff) -> int {
-        const int yy = ybase + a, xx = xbase + b;
-        return (yy < p.H && xx < p.W) ? ((img * p.H + yy) * p.W + xx) * (stride * 4) + choff * 4 + chq : OOB;
-      };
-#pragma unroll
-      for (int nu = 0; nu < 6; ++nu) at6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu]);
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        f32x4 res[4];
-        if (has_e) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) res[b] = bload4(rsE, pix_off(a, b, e_stride, e_choff), 0);
-        }
-        at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          f32x4 v = acc[6 * a + b];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = v[i] >= 0.f ? v[i] : v[i] * p.slope;
-          if (MASK) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= res[b][i] > 0.f ? 1.f : p.mk_slope;
-          } else if (has_e) {
-            v += res[b];
+          for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, W4_SCHED, 0);
+            __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
           }
-          if (has_l) v += bload4(rsL, pix_off(a, b, l_stride, l_choff), 0);
-          bstore4(rsY, pix_off(a, b, p.y_stride, p.y_choff), v);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(c * 4 + s4);
       }
+      LDS_BARRIER();   // V of the next chunk and the halo of the one after it published; everyone is done reading this chunk's
+      STAMP(16 + c);
     }
+    epilogue(img, y0, x0);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(20);
     if (!has_next) break;
     tile = next; img = nimg; y0 = ny0; x0 = nx0;
   }
+#ifdef LFSR_CONV_DIAG
+  if (dbgbuf && tid == 0)
+    for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
+#endif
 }
 
 // U = G g G^t per (n, k) from the direct pack [tap][n][k] -> [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4]
@@ -301,9 +405,13 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino4<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv3x3_wino4<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    const void* fns[5] = {reinterpret_cast<const void*>(k_conv3x3_wino4<false, false, false>), reinterpret_cast<const void*>(k_conv3x3_wino4<false, true, false>),
+                          reinterpret_cast<const void*>(k_conv3x3_wino4<false, true, true>), reinterpret_cast<const void*>(k_conv3x3_wino4<true, true, false>),
+                          reinterpret_cast<const void*>(k_conv3x3_wino4<true, true, true>)};
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+      if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    }
     int v = 0;
     cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     attr_set[dev] = true;
@@ -323,10 +431,16 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
   const long long nt = (long long)n_img * p.tiles_y * p.tiles_x;
   if (nt <= 0 || nt > 0x7fffffffLL) return LFSR_E_ARG;
   p.ntiles = (int)nt;
-  const int slots = W4_BPC * cus[dev];
+  const int slots = cus[dev];
   const unsigned grid = (unsigned)(nt < slots ? nt : slots);
-  if (mk) hipLaunchKernelGGL((k_conv3x3_wino4<true>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
-  else hipLaunchKernelGGL((k_conv3x3_wino4<false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+#ifndef LFSR_CONV_DIAG   // (the diagnostic build passes its stamp buffer as R2)
+  if (!mk && !r1 && r2) { p.R1 = r2; p.r1_stride = r2_stride; p.r1_choff = r2_choff; p.R2 = nullptr; }   // a lone residual is the first operand
+#endif
+  if (mk && p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, true>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+  else if (mk) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+  else if (p.R1 && p.R2) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, true>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+  else if (p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((k_conv3x3_wino4<false, false, false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }

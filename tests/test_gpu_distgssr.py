@@ -116,7 +116,7 @@ def test_conv3x3_bench_size_properties(monkeypatch):
     lin = capi.conv3x3(2.0 * x - 3.0 * z, wp, n_img, h, w, slope=1.0)
     ref = 2.0 * capi.conv3x3(x, wp, n_img, h, w, slope=1.0) - 3.0 * capi.conv3x3(z, wp, n_img, h, w, slope=1.0)
     torch.cuda.synchronize()
-    assert float((lin - ref).abs().max()) < 1e-4
+    assert float((lin - ref).abs().max()) < 2e-5 * float(ref.abs().max())     # (F(4x4,3x3): ~1e-5 relative)
 
 
 @pytest.mark.parametrize("B,A,h,w", GEOMS)

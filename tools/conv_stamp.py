@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lfsr_amd import capi
 capi.LIB_PATH = os.path.abspath(sys.argv[1])
 lib = capi.load()
-n_img, h, w = 800, 32, 32
+n_img, h, w = int(os.environ.get('N_IMG', '800')), 32, 32
 M = n_img * h * w
 x = torch.randn(M, 64, device="cuda"); wt = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
 wp = capi.pack_conv_weight(wt); y = torch.empty(M, 64, device="cuda"); r = torch.randn(M, 64, device="cuda")
@@ -16,7 +16,16 @@ for res in (None, r):
     for _ in range(5):
         capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=res, res2=dbg, out=y)   # R2 carries the debug buffer in the DIAG build
     torch.cuda.synchronize()
-    wino = os.environ.get("LFSR_CONV3X3", "")[:1] != "h"
+    sel = os.environ.get("LFSR_CONV3X3", "")
+    if sel == "":   # F(4x4,3x3) kernel (default): per (chunk, stage) segments, chunk barriers, the epilogue at the head of a pass
+        d = dbg.reshape(256, 32).cpu().double()
+        names = ["chunk %d stage %d" % (k >> 2, k & 3) for k in range(16)] + ["barrier after chunk %d" % c for c in range(4)] + ["epilogue (head of pass)", "last epilogue"]
+        tot = d[:, :22].sum(1).mean()
+        print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block)")
+        for k in range(22):
+            print(f"   {names[k]:28s} {d[:, k].mean():12.0f} cyc  {100 * d[:, k].mean() / tot:5.1f}%   per tile {d[:, k].mean() / (n_img * 4 / 256):9.0f}")
+        continue
+    wino = sel[:1] != "h"
     d = dbg.reshape(256, 32).cpu().double() if wino else dbg.reshape(-1)[:2048].reshape(256, 8).cpu().double()
     if os.environ.get("LFSR_CONV3X3", "")[:1] == "h":
         names = ["9 taps", "seam barrier wait", "transpose+stores", "post-epilogue barrier", "halo LDS write+barrier"]
