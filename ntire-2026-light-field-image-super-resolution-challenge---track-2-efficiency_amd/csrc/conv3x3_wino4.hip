@@ -8,19 +8,14 @@
 // The transform coefficients are small integers (Bt: 1, 2, 4, 5; At: 1, 2, 4, 8) and 1/4, 1/6, 1/12, 1/24 in G, which is applied
 // in fp64 at pack time; round-off of the whole DistgSSR forward stays at 1e-6 (tools/conv_error.py).
 //
-// One 256-thread block = one 8-row x 32-column output tile = 16 Winograd tiles; TWO blocks per CU (75 KB of LDS, <= 256
-// registers each), so one block's epilogue and barrier waits lie under the other block's MFMAs.
-//  * roles.  Every thread is a producer of one (Winograd tile, channel) item per 16-channel chunk: 36 dword loads of its 6x6
-//    patch straight from global memory (16 consecutive lanes = 16 consecutive channels = 64 B runs; zero padding and ragged
-//    edges are out-of-range buffer offsets), the 2-D input transform in registers (144 FMAs), nine ds_write_b128 into the V
-//    buffer of the NEXT chunk.  Every wave is the consumer of one 16-channel slice ns of the OUTPUT channels for all 16 tiles:
-//    v_mfma_f32_16x16x4_f32 with A = U (rows = output channels) and B = V (columns = tiles), 36 accumulators of 4 registers,
-//    so the whole inverse transform At M A happens in registers -- no cross-wave exchange, no seam barriers.
+// One 512-thread block per CU walks 8-row x 32-column output tiles (16 Winograd tiles each):
+//  * v_mfma_f32_16x16x4_f32 with A = U (rows = 16 output channels) and B = V (columns = 16 tiles): 36 accumulators of 4 registers
+//    per wave, so the whole inverse transform At M A happens in registers -- no cross-wave reduction;
 //  * V[parity][tile][channel 0..15][36 positions] in LDS, tile stride 584 floats: the 16-lane groups of ds_read_b128 and the
-//    8-lane groups of ds_write_b128 are both conflict-free.  One barrier per chunk (= per 144 MFMAs of a wave).
+//    8-lane groups of ds_write_b128 are both conflict-free;
 //  * U never touches LDS: the pack is in fragment order [stage k/4][ns][p/4][lane][p%4], a wave streams its 9 KB per stage
-//    through a register ring of 16-B fragments (L2 hits, 1 KB contiguous per wave instruction).
-//  * epilogue from registers: lane = (tile, 4 consecutive output channels) -> 16-B stores / residual loads per pixel.
+//    through a register ring of 16-B fragments (L2 hits, 1 KB contiguous per wave instruction);
+//  * the waves are specialised (see the kernel): four consume (MFMA), four produce (patch loads, input transform, epilogue I/O).
 #include <stdlib.h>
 
 #include "lfsr_internal.h"
@@ -29,13 +24,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W4_ABL
-#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no halo loads, 2 no halo stores, 4 no V writes, 8 no patch reads / input transform, 16 no U loads, 32 no epilogue stores, 64 no second-operand loads, 128 no first-operand loads
+#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no patch loads, 2 no input transform, 4 no V writes, 16 no U loads, 32 a quarter of the epilogue stores
 #endif
 #ifndef W4_BPC
 #define W4_BPC 1      // blocks per CU: 2 (<= 256 registers per wave) or 1 (<= 512)
 #endif
 #ifndef W4_SCHED
 #define W4_SCHED 4    // VALU instructions dealt out per MFMA gap (0: leave the stage to the compiler's scheduler)
+#endif
+#ifndef W4_VRING
+#define W4_VRING 4    // depth of the V fragment ring (LDS reads W4_VRING - 1 groups ahead); must divide 36
 #endif
 #ifndef W4_URING
 #define W4_URING 12   // depth of the U fragment ring (16-B fragments in flight per wave); must divide 144
@@ -55,7 +53,7 @@ constexpr int VBUF = 16 * TS;           // one parity
 constexpr int HPIX = 10 * 34;           // raw halo of an 8 x 32 tile
 constexpr int HPS = 20;                 // floats per halo pixel in LDS (16 channels of the chunk + 4: adjacent tiles 16 banks apart)
 constexpr int HBUF = HPIX * HPS;        // one parity
-constexpr int SMEM_BYTES = (2 * VBUF + 2 * HBUF + 256 + 2 * 4096) * 4;   // 162944: V, halo, 1 KB landing zone for the unused halo slots, epilogue exchange
+constexpr int SMEM_BYTES = (2 * VBUF + 2 * 4096) * 4;   // 107520: V, epilogue exchange
 constexpr int INV = 1 << 30;            // "outside the image" marker of a row / column offset (operands span < 1 GiB)
 constexpr int OOB = (int)0x80000000u;
 
@@ -102,260 +100,220 @@ __device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, 
   m3 = (d12 + 8.f * d34) + m5;
 }
 
-// HAS_E / HAS_L: the first (residual R1, or the saved activation of the LeakyReLU' mask) / second epilogue operand exists.  An absent
-// operand must not even be requested: vector memory operations retire in order, a load queued behind the previous round's stores
-// waits for them
+// HAS_E / HAS_L: the first (residual R1, or the saved activation of the LeakyReLU' mask) / second epilogue operand exists.
+//
+// Wave specialisation (512 threads = 8 waves, two per SIMD, <= 256 registers):
+//   waves 0..3  CONSUMERS -- wave ns owns output channels 16 ns .. 16 ns + 15 of all 16 Winograd tiles: U fragments straight from
+//               L2 through a register ring, V fragments from LDS, 576 MFMAs per tile into 36 accumulators, then At M A in registers
+//               and the raw conv result -> the LDS exchange buffer, one output row of every Winograd tile per round.  Their vector
+//               memory queue holds nothing but U loads (L2 hits): vector memory operations return in order, so a single HBM miss or
+//               store burst in that queue holds up every U fragment queued behind it (measured: 5-6k cycles per tile).
+//   waves 4..7  PRODUCERS -- all other global traffic.  Per 16-channel chunk one (Winograd tile, channel) item per thread: 36 dword
+//               loads of its 6x6 patch (16 consecutive lanes = 16 consecutive channels; zero padding and ragged edges are out-of-
+//               range buffer offsets), Bt d B in registers, nine ds_write_b128 into the V buffer of the next chunk; per epilogue
+//               round they read the exchange buffer back as whole pixels (16 B per lane, 256 B contiguous per pixel), apply
+//               LeakyReLU / mask / residuals and store.  Their loads miss to HBM and their stores drain while the consumer of the
+//               same SIMD keeps the matrix pipe busy.
+// Barriers per tile: one per chunk (V of the next chunk published, this chunk's V free) + one per exchange round.
 template <bool MASK, bool HAS_E, bool HAS_L>
-__global__ __launch_bounds__(256, 1) void k_conv3x3_wino4(Wino4Args p) {
+__global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const sV = smem;                               // V[2][16 tiles][16 ch][36]
-  float* const sH = smem + 2 * VBUF;                    // raw halo of one 16-channel chunk: [2][340 pixels][20] (16 used)
-  float* const sX = smem + 2 * VBUF + 2 * HBUF + 256;   // epilogue exchange: [2][64 pixels][64 channels]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* const sV = smem;                 // V[2][16 tiles][16 ch][36]
+  float* const sX = smem + 2 * VBUF;      // epilogue exchange: [2][64 pixels][64 channels]
+  const int tid = threadIdx.x & 255, lane = tid & 63, w4 = (threadIdx.x >> 6) & 3;
+  const bool producer = threadIdx.x >= 256;
   const int nblk = gridDim.x;
-  // producer item: channel c16 of Winograd tile ptile = (pty, ptx); consumer fragment: tile ctile, channel 4 s + kk of a stage
-  const int c16 = lane & 15, ptile = 4 * wave + (lane >> 4), pty = ptile >> 3, ptx = ptile & 7;
-  const int ctile = lane & 15, kk = lane >> 4, cty = ctile >> 3, ctx = ctile & 7;
-  const int ns = wave;
-
+  // a block walks a CONTIGUOUS range of tiles (the next tile's patch rows share pages and two pixel rows with this one's)
+  int tile = (int)(((long long)blockIdx.x * p.ntiles) / nblk);
+  const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.ntiles) / nblk);
 #ifdef LFSR_CONV_DIAG
+  const int wave = threadIdx.x >> 6;
   long long seg[32] = {};
   long long tprev = clock64();
   float* dbgbuf = const_cast<float*>(p.R2);
   p.R2 = nullptr;
 #endif
-  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, OOB), rsW = make_rsrc(p.Wu, 36 * 64 * 64 * 4), rsY = make_rsrc(p.Y, OOB);
-  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, (MASK ? p.Mk : p.R1) ? OOB : 0);   // first epilogue operand
-  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(MASK ? p.R1 : p.R2, (MASK ? p.R1 : p.R2) ? OOB : 0);   // second epilogue operand
-  const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
-  const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
 
-  // a block walks a CONTIGUOUS range of tiles: the next tile's halo shares two pixel rows (and its pages) with this one's
-  int tile = (int)(((long long)blockIdx.x * p.ntiles) / nblk);
-  const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.ntiles) / nblk);
-  auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
-    int txx = t % p.tiles_x; int q = t / p.tiles_x;
-    int tyy = q % p.tiles_y; img = q / p.tiles_y;
-    y0 = tyy * 8; x0 = txx * 32;
-  };
-  // ---- halo staging: slot i of a thread = (halo pixel, 16-B quarter of the chunk's 64 B) = (idx >> 2, idx & 3), idx = tid + 256 i
-  int hx[6];   // global byte offsets (chunk 0) of the tile whose halo is being fetched; OOB outside the image
-  auto halo_offsets = [&](bool valid, int img, int y0, int x0) {
-    const int base = (((img * p.H + y0 - 1) * p.W + x0 - 1) * p.x_stride + p.x_choff) * 4;   // wave-uniform
+  if (producer) {
+    // ======================================================= PRODUCER ==========================================================
+    const int c16 = lane & 15, ptile = 4 * w4 + (lane >> 4), pty = ptile >> 3, ptx = ptile & 7;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.Y, OOB);
+    const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, OOB), rsL = make_rsrc(MASK ? p.R1 : p.R2, OOB);
+    const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
+    const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
+    auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
+      int txx = t % p.tiles_x; int q = t / p.tiles_x;
+      int tyy = q % p.tiles_y; img = q / p.tiles_y;
+      y0 = tyy * 8; x0 = txx * 32;
+    };
+    // byte offsets of the 6 patch rows and 6 patch columns (sum = element offset; INV in either -> beyond the descriptor's range)
+    int ro[6], co[6];
+    auto patch_offsets = [&](bool valid, int img, int y0, int x0) {
+      if (W4_ABL & 8) { img = blockIdx.x & 7; y0 = 0; x0 = 0; }   // (timing ablation: every tile reads the same few patches -- cache hits only)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int px = (tid + 256 * i) >> 2, cq = tid & 3;
-      const int r = __mul24(px, 1928) >> 16;   // px / 34 for px < 384
-      const int c = px - r * 34;
-      const int yy = y0 + r - 1, xx = x0 + c - 1;
-      const bool ok = valid && px < HPIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-      hx[i] = ok ? base + __mul24(__mul24(r, p.W) + c, p.x_stride * 4) + cq * 16 : OOB;
-    }
-  };
-  f32x4 hv[6];
-  auto halo_load = [&](int chunk) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) hv[i] = bload4(rsX, hx[i], chunk * 64);
-  };
-  auto halo_store = [&](int par, int i0, int i1) {
-#pragma unroll
-    for (int i = i0; i < i1; ++i) {
-      const int px = (tid + 256 * i) >> 2, cq = tid & 3;
-      float* dst = (i < 5 || px < HPIX) ? sH + par * HBUF + px * HPS + cq * 4 : smem + 2 * VBUF + 2 * HBUF + (tid & 63) * 4;   // slots 340..383: landing zone
-      *reinterpret_cast<f32x4*>(dst) = hv[i];
-    }
-  };
-  // ---- producer: 6x6 patch of (ptile, c16) from the staged halo, Bt d B in registers, 36 values into V -----------------------
-  const float* const hR = sH + ((4 * pty) * 34 + 4 * ptx) * HPS + c16;
-  float raw[36];
-  auto read_raw = [&](int par) {
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = 0; c < 6; ++c) raw[6 * r + c] = hR[par * HBUF + (r * 34 + c) * HPS];
-  };
-  auto transform_cols = [&]() {
-#pragma unroll
-    for (int c = 0; c < 6; ++c) bt6(raw[c], raw[6 + c], raw[12 + c], raw[18 + c], raw[24 + c], raw[30 + c]);
-  };
-  auto transform_rows = [&]() {
-#pragma unroll
-    for (int r = 0; r < 6; ++r) bt6(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2], raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5]);
-  };
-  float* const vW = sV + ptile * TS + c16 * 36;          // producer's 36 floats (parity 0)
-  const float* const vR = sV + ctile * TS + kk * 36;     // consumer's fragment base (parity 0, stage 0): + s4 * 144 + 4 q
-  auto write_v = [&](int par, int q0, int q1) {
-#pragma unroll
-    for (int q = q0; q < q1; ++q) {
-      f32x4 v; v.x = raw[4 * q]; v.y = raw[4 * q + 1]; v.z = raw[4 * q + 2]; v.w = raw[4 * q + 3];
-      *reinterpret_cast<f32x4*>(vW + par * VBUF + 4 * q) = v;
-    }
-  };
-  const int uoff = ns * 9216 + lane * 16;   // byte offset of this lane's U fragments within a stage (q = 0)
-
-  int img, y0, x0;
-  tile_origin(tile, img, y0, x0);
-
-  // ---- prologue: halo chunks 0 and 1 staged, chunk 2 in flight, V of chunk 0 in buffer 0, U ring filled ------------------------
-  halo_offsets(true, img, y0, x0);
-  halo_load(0); halo_store(0, 0, 6);
-  halo_load(1); halo_store(1, 0, 6);
-  halo_load(2);
-  f32x4 U[W4_URING];
-#pragma unroll
-  for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, uoff, ((i / 9) * 36 + (i % 9)) * 1024);
-  LDS_BARRIER();
-  read_raw(0); transform_cols(); transform_rows(); write_v(0, 0, 9);
-  LDS_BARRIER();
-
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 acc[36];
-
-  // ---- epilogue of one tile (img, y0, x0): At M A in registers, then -- one output row a of every Winograd tile per round -- the
-  // 64 pixels x 64 channels of the round go through LDS so that every global access is 16 B per lane, 256 B contiguous per pixel
-  // (straight from the accumulator layout a store instruction would touch sixteen separate 64-B pieces: measured 4x slower)
-  const int xw = (cty * 32 + 4 * ctx) * 64 + (((4 * ns + kk) ^ ctx) << 2);   // writer: pixel (row cty, col 4 ctx + b), 16-B unit XOR ctx
-  // reader slots of a round: (pixel, unit) = (idx >> 4, idx & 15), idx = tid + 256 i
-  auto reader_pix = [&](int a, int i, int eimg, int ey0, int ex0) -> int {
-    const int px = (tid + 256 * i) >> 4;
-    const int yy = ey0 + 4 * (px >> 5) + a, xx = ex0 + (px & 31);
-    return (yy < p.H && xx < p.W) ? (eimg * p.H + yy) * p.W + xx : -1;
-  };
-  f32x4 eop[HAS_E ? 8 : 1];   // rounds a and a + 1
-  // first-operand loads k = 4 a + i of rounds a = k / 4 (slots eop[k % 8]): rounds 0 and 1 are requested during the last stage of the
-  // K loop, round a + 2 between the arithmetic and the stores of round a -- never behind a store of its own tile
-  auto epilogue_request = [&](int eimg, int ey0, int ex0, int k0, int k1) {
-    if (HAS_E) {
-#pragma unroll
-      for (int k = k0; k < k1; ++k) {
-        const int pix = reader_pix(k >> 2, k & 3, eimg, ey0, ex0);
-        eop[HAS_E ? k & 7 : 0] = bload4(rsE, pix >= 0 ? pix * (e_stride * 4) + e_choff * 4 + (tid & 15) * 16 : OOB, 0);
+      for (int r = 0; r < 6; ++r) {
+        const int yy = y0 + 4 * pty - 1 + r;
+        ro[r] = (valid && (unsigned)yy < (unsigned)p.H) ? ((img * p.H + yy) * p.W) * (p.x_stride * 4) : INV;
       }
-    }
-  };
-  auto epilogue = [&](int eimg, int ey0, int ex0) {
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) at6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu]);
+      for (int c = 0; c < 6; ++c) {
+        const int xx = x0 + 4 * ptx - 1 + c;
+        co[c] = ((unsigned)xx < (unsigned)p.W) ? xx * (p.x_stride * 4) + (p.x_choff + c16) * 4 : INV;
+      }
+    };
+    // the patch of chunk k lives in raw[k & 1]; it is requested two chunks (~10k cycles) before its transform: a tile's first chunk
+    // is the first touch of its pixels
+    float raw0[36], raw1[36];
+    auto load_raw = [&](float (&raw)[36], int chunk) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      float* const xb = sX + (a & 1) * 4096;
-      at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
+      for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(ro[r]));   // the 36 sums are formed here, not kept across the tile
 #pragma unroll
-      for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(xb + xw + b * 64) = acc[6 * a + b];
-      LDS_BARRIER();
-      f32x4 vo[4];
+      for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int px = (tid + 256 * i) >> 4, un = tid & 15;
-        f32x4 v = *reinterpret_cast<const f32x4*>(xb + px * 64 + ((un ^ ((px >> 2) & 7)) << 2));
+        for (int c = 0; c < 6; ++c) raw[6 * r + c] = bload1(rsX, ro[r] + co[c], chunk * 64);
+    };
+    auto transform = [&](float (&raw)[36]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
-        if (MASK) {
+      for (int c = 0; c < 6; ++c) bt6(raw[c], raw[6 + c], raw[12 + c], raw[18 + c], raw[24 + c], raw[30 + c]);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] *= eop[HAS_E ? 4 * (a & 1) + i : 0][k] > 0.f ? 1.f : p.mk_slope;
-        } else if (HAS_E) {
-          v += eop[HAS_E ? 4 * (a & 1) + i : 0];
+      for (int r = 0; r < 6; ++r) bt6(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2], raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5]);
+    };
+    float* const vW = sV + ptile * TS + c16 * 36;
+    auto write_v = [&](float (&raw)[36], int par) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        f32x4 v; v.x = raw[4 * q]; v.y = raw[4 * q + 1]; v.z = raw[4 * q + 2]; v.w = raw[4 * q + 3];
+        *reinterpret_cast<f32x4*>(vW + par * VBUF + 4 * q) = v;
+      }
+    };
+    // epilogue reader slots of a round a: (pixel, 16-B unit) = (idx >> 4, idx & 15), idx = tid + 256 i
+    auto reader_pix = [&](int a, int i, int eimg, int ey0, int ex0) -> int {
+      const int px = (tid + 256 * i) >> 4;
+      const int yy = ey0 + 4 * (px >> 5) + a, xx = ex0 + (px & 31);
+      return (yy < p.H && xx < p.W) ? (eimg * p.H + yy) * p.W + xx : -1;
+    };
+
+    int img, y0, x0;
+    tile_origin(tile, img, y0, x0);
+    patch_offsets(true, img, y0, x0);
+    load_raw(raw0, 0);
+    transform(raw0);
+    write_v(raw0, 0);
+    load_raw(raw1, 1);
+    load_raw(raw0, 2);
+    LDS_BARRIER();   // (B0)
+    while (true) {
+      const int next = tile + 1;
+      const bool has_next = next < tile_end;
+      int nimg = 0, ny0 = 0, nx0 = 0;
+      if (has_next) tile_origin(next, nimg, ny0, nx0);
+      f32x4 eop[HAS_E ? 16 : 1];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        // chunk c + 1 (chunk 0 of the next tile when c == 3): transform, V -> the other buffer; then request chunk c + 3 into its registers
+        float (&raw)[36] = ((c + 1) & 1) ? raw1 : raw0;
+        if (!(W4_ABL & 2)) transform(raw);
+        if (!(W4_ABL & 4)) write_v(raw, (c + 1) & 1);
+        if (c == 1) patch_offsets(has_next, nimg, ny0, nx0);
+        if (!(W4_ABL & 1)) load_raw(raw, (c + 3) & 3);
+        if (c == 3 && HAS_E) {   // this tile's first epilogue operand, all four rounds
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int pix = reader_pix(k >> 2, k & 3, img, y0, x0);
+            eop[HAS_E ? k : 0] = bload4(rsE, pix >= 0 ? pix * (e_stride * 4) + e_choff * 4 + (tid & 15) * 16 : OOB, 0);
+          }
         }
-        vo[i] = v;
-      }
-      if (a < 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue_request(eimg, ey0, ex0, 4 * (a + 2), 4 * (a + 2) + 4);
-        __builtin_amdgcn_sched_barrier(0);
+        LDS_BARRIER();
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int un = tid & 15;
-        const int pix = reader_pix(a, i, eimg, ey0, ex0);
-        f32x4 v = vo[i];
-        if (HAS_L) v += bload4(rsL, pix >= 0 ? pix * (l_stride * 4) + l_choff * 4 + un * 16 : OOB, 0);   // (rare: waits for the stores ahead of it)
-        bstore4(rsY, pix >= 0 ? pix * (p.y_stride * 4) + p.y_choff * 4 + un * 16 : OOB, v);
-      }
-    }
-  };
-
-  // One tile = 4 chunks x 4 stages x 9 fragment groups x 4 MFMAs.  In the same instruction stream, per chunk g (parity par):
-  //   stage 0: patch of chunk g + 1 from the staged halo;   stage 1: column transform, first half of the halo of chunk g + 2 (in
-  //   registers since the previous chunk) -> LDS;   stages 2, 3: row transform and V of chunk g + 1 -> the other V buffer, half each;
-  //   second half of the halo -> LDS (2), request the halo of chunk g + 3 (3);   barrier.
-  while (true) {
-    const int next = tile + 1;
-    const bool has_next = next < tile_end;
-    int nimg = 0, ny0 = 0, nx0 = 0;
-    if (has_next) tile_origin(next, nimg, ny0, nx0);
+      for (int a = 0; a < 4; ++a) {
+        LDS_BARRIER();   // round a of the consumers' results is in the exchange buffer
+        const float* const xb = sX + (a & 1) * 4096;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int par = c & 1;
-      f32x4 Vq[3];
-      Vq[0] = *reinterpret_cast<const f32x4*>(vR + par * VBUF);
-      Vq[1] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + 4);
+        for (int i = 0; i < 4; ++i) {
+          const int px = (tid + 256 * i) >> 4, un = tid & 15;
+          const int pix = reader_pix(a, i, img, y0, x0);
+          f32x4 v = *reinterpret_cast<const f32x4*>(xb + px * 64 + ((un ^ ((px >> 2) & 7)) << 2));
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
+          for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+          if (MASK) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const int t = (c * 4 + s4) * 9 + q;      // fragment group of the tile, 0..143
-          const int g = s4 * 9 + q;                // ... of the chunk
-          if (g + 2 < 36) Vq[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + ((g + 2) / 9) * 144 + ((g + 2) % 9) * 4);
-          // -- this group's slice of the producer work (the scheduler may not move anything across a group: one wave per SIMD,
-          //    nobody else fills an MFMA gap, and an LDS read parked right in front of its use exposes the whole LDS latency)
-          if (s4 == 0 && !(W4_ABL & 8)) {
-#pragma unroll
-            for (int e = 4 * q; e < 4 * q + 4; ++e) raw[e] = hR[(par ^ 1) * HBUF + ((e / 6) * 34 + e % 6) * HPS];
+            for (int k = 0; k < 4; ++k) v[k] *= eop[HAS_E ? 4 * a + i : 0][k] > 0.f ? 1.f : p.mk_slope;
+          } else if (HAS_E) {
+            v += eop[HAS_E ? 4 * a + i : 0];
           }
-          if (s4 == 1) {
-            if (q < 6 && !(W4_ABL & 8)) bt6(raw[q], raw[6 + q], raw[12 + q], raw[18 + q], raw[24 + q], raw[30 + q]);
-            if (q >= 6 && !(W4_ABL & 2)) halo_store(par, q - 6, q - 5);
-          }
-          if (s4 == 2 && !(W4_ABL & 8)) {
-            if (q < 6) bt6(raw[6 * q], raw[6 * q + 1], raw[6 * q + 2], raw[6 * q + 3], raw[6 * q + 4], raw[6 * q + 5]);
-            if (!(W4_ABL & 4)) {   // fragment j needs rows <= (4 j + 3) / 6: one write per group, a group behind its last row
-              if (q >= 1 && q <= 5) write_v(par ^ 1, q - 1, q);
-              if (q == 6) write_v(par ^ 1, 5, 7);
-              if (q == 7) write_v(par ^ 1, 7, 8);
-              if (q == 8) write_v(par ^ 1, 8, 9);
-            }
-          }
-          if (s4 == 3) {
-            if (q < 3 && !(W4_ABL & 2)) halo_store(par, 3 + q, 4 + q);
-            if (q == 2 && c == 1) halo_offsets(has_next, nimg, ny0, nx0);   // chunk g + 3 is chunk 0 of the next tile from here on
-            if (q >= 3 && !(W4_ABL & 1)) hv[q - 3] = bload4(rsX, hx[q - 3], ((c + 3) & 3) * 64);
-            if (c == 3 && q < 8) epilogue_request(img, y0, x0, q, q + 1);
-          }
-          // -- consumer
-          const f32x4 u = U[t % W4_URING], v = Vq[g % 3];
-          const bool first = (c == 0 && s4 == 0);
-          acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v.x, first ? zero4 : acc[4 * q + 0], 0, 0, 0);
-          acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v.y, first ? zero4 : acc[4 * q + 1], 0, 0, 0);
-          acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[4 * q + 2], 0, 0, 0);
-          acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[4 * q + 3], 0, 0, 0);
-          const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
-          if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
-          // a 16x16x4 fp32 MFMA holds the matrix pipe for 32 cycles and the wave's issue slot for 4-8: the group's other
-          // instructions go between its four MFMAs
-#if W4_SCHED
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, W4_SCHED, 0);
-            __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-          }
-#endif
-          __builtin_amdgcn_sched_barrier(0);
+          if (HAS_L) v += bload4(rsL, pix >= 0 ? pix * (l_stride * 4) + l_choff * 4 + un * 16 : OOB, 0);
+          if (!(W4_ABL & 32) || i == 0) bstore4(rsY, pix >= 0 ? pix * (p.y_stride * 4) + p.y_choff * 4 + un * 16 : OOB, v);
         }
-        STAMP(c * 4 + s4);
       }
-      LDS_BARRIER();   // V of the next chunk and the halo of the one after it published; everyone is done reading this chunk's
-      STAMP(16 + c);
+      if (!has_next) break;
+      tile = next; img = nimg; y0 = ny0; x0 = nx0;
     }
-    epilogue(img, y0, x0);
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(20);
-    if (!has_next) break;
-    tile = next; img = nimg; y0 = ny0; x0 = nx0;
+  } else {
+    // ======================================================= CONSUMER ==========================================================
+    const int ctile = lane & 15, kk = lane >> 4, cty = ctile >> 3, ctx = ctile & 7;
+    const int ns = w4;
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wu, 36 * 64 * 64 * 4);
+    const float* const vR = sV + ctile * TS + kk * 36;     // fragment base (parity 0, stage 0): + s4 * 144 + 4 q
+    const int uoff = ns * 9216 + lane * 16;                // byte offset of this lane's U fragments within a stage (q = 0)
+    const int xw = (cty * 32 + 4 * ctx) * 64 + (((4 * ns + kk) ^ ctx) << 2);   // exchange: pixel (row cty, col 4 ctx + b), 16-B unit XOR ctx
+    f32x4 U[W4_URING];
+#pragma unroll
+    for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, uoff, ((i / 9) * 36 + (i % 9)) * 1024);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[36];
+    LDS_BARRIER();   // (B0)
+    STAMP(31);
+    while (true) {
+      const bool has_next = tile + 1 < tile_end;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int par = c & 1;
+        f32x4 Vq[W4_VRING];
+#pragma unroll
+        for (int i = 0; i < W4_VRING - 1; ++i) Vq[i] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + 4 * i);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const int t = (c * 4 + s4) * 9 + q;      // fragment group of the tile, 0..143
+            const int g = s4 * 9 + q;                // ... of the chunk
+            constexpr int VA = W4_VRING - 1;         // LDS reads run VA groups ahead of their use
+            if (g + VA < 36) Vq[(g + VA) % W4_VRING] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + ((g + VA) / 9) * 144 + ((g + VA) % 9) * 4);
+            const f32x4 u = U[t % W4_URING], v = Vq[g % W4_VRING];
+            const bool first = (c == 0 && s4 == 0);
+            acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v.x, first ? zero4 : acc[4 * q + 0], 0, 0, 0);
+            acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v.y, first ? zero4 : acc[4 * q + 1], 0, 0, 0);
+            acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[4 * q + 2], 0, 0, 0);
+            acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[4 * q + 3], 0, 0, 0);
+            const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
+            if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
+            __builtin_amdgcn_sched_barrier(0);       // (keeps every LDS read two groups ahead of its use)
+          }
+        }
+        STAMP(c);
+        LDS_BARRIER();   // V of the next chunk published; everyone is done reading this chunk's
+        STAMP(16 + c);
+      }
+      // At M A in registers; one output row a of every Winograd tile per round -> exchange buffer
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) at6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float* const xb = sX + (a & 1) * 4096;
+        at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(xb + xw + b * 64) = acc[6 * a + b];
+        STAMP(8 + a);
+        LDS_BARRIER();
+        STAMP(20 + a);
+      }
+      if (!has_next) break;
+      tile += 1;
+    }
   }
 #ifdef LFSR_CONV_DIAG
-  if (dbgbuf && tid == 0)
+  if (dbgbuf && threadIdx.x == 0)
     for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
 #endif
 }
@@ -436,11 +394,11 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
 #ifndef LFSR_CONV_DIAG   // (the diagnostic build passes its stamp buffer as R2)
   if (!mk && !r1 && r2) { p.R1 = r2; p.r1_stride = r2_stride; p.r1_choff = r2_choff; p.R2 = nullptr; }   // a lone residual is the first operand
 #endif
-  if (mk && p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, true>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
-  else if (mk) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
-  else if (p.R1 && p.R2) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, true>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
-  else if (p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
-  else hipLaunchKernelGGL((k_conv3x3_wino4<false, false, false>), dim3(grid), dim3(256), SMEM_BYTES, st, p);
+  if (mk && p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else if (mk) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else if (p.R1 && p.R2) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else if (p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  else hipLaunchKernelGGL((k_conv3x3_wino4<false, false, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }

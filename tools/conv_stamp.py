@@ -19,10 +19,12 @@ for res in (None, r):
     sel = os.environ.get("LFSR_CONV3X3", "")
     if sel == "":   # F(4x4,3x3) kernel (default): per (chunk, stage) segments, chunk barriers, the epilogue at the head of a pass
         d = dbg.reshape(256, 32).cpu().double()
-        names = ["chunk %d stage %d" % (k >> 2, k & 3) for k in range(16)] + ["barrier after chunk %d" % c for c in range(4)] + ["epilogue (head of pass)", "last epilogue"]
-        tot = d[:, :22].sum(1).mean()
+        names = (["chunk %d MFMA stream" % k for k in range(4)] + ["-"] * 4 + ["epilogue round %d (first: + column pass)" % a for a in range(4)] + ["-"] * 4
+                 + ["barrier after chunk %d" % c for c in range(4)] + ["barrier of round %d" % a for a in range(4)])
+        tot = d[:, :24].sum(1).mean()
         print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block)")
-        for k in range(22):
+        for k in range(24):
+            if names[k] == '-': continue
             print(f"   {names[k]:28s} {d[:, k].mean():12.0f} cyc  {100 * d[:, k].mean() / tot:5.1f}%   per tile {d[:, k].mean() / (n_img * 4 / 256):9.0f}")
         continue
     wino = sel[:1] != "h"
