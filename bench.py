@@ -183,13 +183,16 @@ def main():
         M = BATCH * A * A * H * W
         conv_flop = 2.0 * 576 * 64 * M
         ach = conv_flop / (conv_avg_ms * 1e-3) / 1e12
-        direct = os.environ.get("LFSR_CONV3X3", "")[:1] in ("h", "g")
-        tiles = M // 256                      # 8 x 32-pixel tiles
-        # flops the MFMA pipe actually executes per op: a Winograd tile is 16 position-GEMMs of 2 x 64 x 64 x 64 (a direct tile 9 x 2 x 256 x 64 x 64)
-        exec_flop = conv_flop if direct else tiles * 16 * 2.0 * 64 * 64 * 64
+        sel = os.environ.get("LFSR_CONV3X3", "")
+        direct = sel[:1] in ("h", "g")
+        wino2 = sel[:5] == "wino2"
+        # flops the MFMA pipe actually executes per op: per 8 x 32-pixel tile F(4x4,3x3) runs 36 position-GEMMs of 16 tiles x 64 x 64
+        # (2.25 multiplies per output and channel pair), F(2x2,3x3) 16 of 64 tiles x 64 x 64 (4), the direct form 9 taps (9)
+        exec_flop = conv_flop if direct else conv_flop * (4.0 / 9.0 if wino2 else 2.25 / 9.0)
         kname = ("k_conv3x3_halo (direct 9-tap halo-tile kernel + channel-split tail launch)" if direct else
-                 "k_conv3x3_wino (per-view 3x3 64->64 in Winograd F(2x2,3x3) form: persistent 8x32 tiles, 16 position-GEMMs on fp32 MFMA "
-                 "32x32x2, in-place halo streaming; one launch: persistent body blocks + channel-split blocks for the leftover tiles)")
+                 "k_conv3x3_wino (Winograd F(2x2,3x3): persistent 8x32 tiles, 16 position-GEMMs on fp32 MFMA 32x32x2, in-place halo streaming)" if wino2 else
+                 "k_conv3x3_wino4 (per-view 3x3 64->64 in Winograd F(4x4,3x3) form: persistent 8x32-pixel tiles, 36 position-GEMMs on fp32 MFMA "
+                 "16x16x4 with the inverse transform in registers; 4 MFMA consumer waves + 4 producer waves per CU, V through LDS, U streamed from L2)")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
         if os.path.exists(pmc):
@@ -210,8 +213,8 @@ def main():
                          "kernel": kname + "; duration = one conv op",
                          "flop_per_launch": conv_flop, "executed_flop_per_launch": exec_flop,
                          "mfma_util": exec_flop / (conv_avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "note": "achieved = algorithmic direct-conv flops (SURVEY 8d) / time; the Winograd form issues 2.25x fewer MFMA "
-                                 "flops, so frac may exceed 1 -- mfma_util is the matrix-pipe utilisation",
+                         "note": "achieved = algorithmic direct-conv flops (SURVEY 8d) / time; the Winograd F(4x4,3x3) form issues 4x fewer MFMA "
+                                 "flops (F(2x2,3x3): 2.25x), so frac may exceed 1 -- mfma_util is the matrix-pipe utilisation",
                          "avg_launch_ms": conv_avg_ms, "launches_timed": conv_n},
             "model_tflops": FLOP_PER_PATCH * world * BATCH * args.steps / el / 1e12,
             "kernel_ms_per_step": {k: v[0] / nb for k, v in prof_all.items()},

@@ -53,7 +53,7 @@ constexpr int VBUF = 16 * TS;           // one parity
 constexpr int HPIX = 10 * 34;           // raw halo of an 8 x 32 tile
 constexpr int HPS = 20;                 // floats per halo pixel in LDS (16 channels of the chunk + 4: adjacent tiles 16 banks apart)
 constexpr int HBUF = HPIX * HPS;        // one parity
-constexpr int SMEM_BYTES = (2 * VBUF + 2 * 4096) * 4;   // 107520: V, epilogue exchange
+constexpr int SMEM_BYTES = (2 * VBUF + 4 * 4096) * 4;   // 140288: V, epilogue exchange (one 64-pixel x 64-channel plane per output row of the Winograd tiles)
 constexpr int INV = 1 << 30;            // "outside the image" marker of a row / column offset (operands span < 1 GiB)
 constexpr int OOB = (int)0x80000000u;
 
@@ -110,16 +110,16 @@ __device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, 
 //               store burst in that queue holds up every U fragment queued behind it (measured: 5-6k cycles per tile).
 //   waves 4..7  PRODUCERS -- all other global traffic.  Per 16-channel chunk one (Winograd tile, channel) item per thread: 36 dword
 //               loads of its 6x6 patch (16 consecutive lanes = 16 consecutive channels; zero padding and ragged edges are out-of-
-//               range buffer offsets), Bt d B in registers, nine ds_write_b128 into the V buffer of the next chunk; per epilogue
-//               round they read the exchange buffer back as whole pixels (16 B per lane, 256 B contiguous per pixel), apply
-//               LeakyReLU / mask / residuals and store.  Their loads miss to HBM and their stores drain while the consumer of the
+//               range buffer offsets), Bt d B in registers, nine ds_write_b128 into the V buffer of the next chunk; and per chunk
+//               one exchange plane of the PREVIOUS tile read back as whole pixels (16 B per lane, 256 B contiguous per pixel),
+//               LeakyReLU / mask / residuals applied, stored.  Their loads miss to HBM and their stores drain while the consumer of the
 //               same SIMD keeps the matrix pipe busy.
-// Barriers per tile: one per chunk (V of the next chunk published, this chunk's V free) + one per exchange round.
+// Barriers per tile: one per chunk (V of the next chunk published, this chunk's V free) + one for the exchange buffer.
 template <bool MASK, bool HAS_E, bool HAS_L>
 __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const sV = smem;                 // V[2][16 tiles][16 ch][36]
-  float* const sX = smem + 2 * VBUF;      // epilogue exchange: [2][64 pixels][64 channels]
+  float* const sX = smem + 2 * VBUF;      // epilogue exchange: [4 rows a][64 pixels][64 channels]
   const int tid = threadIdx.x & 255, lane = tid & 63, w4 = (threadIdx.x >> 6) & 3;
   const bool producer = threadIdx.x >= 256;
   const int nblk = gridDim.x;
@@ -193,7 +193,35 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       return (yy < p.H && xx < p.W) ? (eimg * p.H + yy) * p.W + xx : -1;
     };
 
+    int pix[4];
+    f32x4 e[4];
+    auto drain_request = [&](int a, int eimg, int ey0, int ex0) {   // pixel slots of plane a and their first operand (ahead of the patch loads)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pix[i] = eimg >= 0 ? reader_pix(a, i, eimg, ey0, ex0) : -1;
+        if (HAS_E) e[i] = bload4(rsE, pix[i] >= 0 ? pix[i] * (e_stride * 4) + e_choff * 4 + (tid & 15) * 16 : OOB, 0);
+      }
+    };
+    auto drain_plane = [&](int a) {
+      const float* const xb = sX + a * 4096;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int px = (tid + 256 * i) >> 4, un = tid & 15;
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + px * 64 + ((un ^ ((px >> 2) & 7)) << 2));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+        if (MASK) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] *= e[i][k] > 0.f ? 1.f : p.mk_slope;
+        } else if (HAS_E) {
+          v += e[i];
+        }
+        if (HAS_L) v += bload4(rsL, pix[i] >= 0 ? pix[i] * (l_stride * 4) + l_choff * 4 + un * 16 : OOB, 0);
+        if (!(W4_ABL & 32) || i == 0) bstore4(rsY, pix[i] >= 0 ? pix[i] * (p.y_stride * 4) + p.y_choff * 4 + un * 16 : OOB, v);
+      }
+    };
     int img, y0, x0;
+    int pimg = -1, py0 = 0, px0 = 0;
     tile_origin(tile, img, y0, x0);
     patch_offsets(true, img, y0, x0);
     load_raw(raw0, 0);
@@ -207,46 +235,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       const bool has_next = next < tile_end;
       int nimg = 0, ny0 = 0, nx0 = 0;
       if (has_next) tile_origin(next, nimg, ny0, nx0);
-      f32x4 eop[HAS_E ? 16 : 1];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         // chunk c + 1 (chunk 0 of the next tile when c == 3): transform, V -> the other buffer; then request chunk c + 3 into its registers
         float (&raw)[36] = ((c + 1) & 1) ? raw1 : raw0;
+        drain_request(c, pimg, py0, px0);
         if (!(W4_ABL & 2)) transform(raw);
         if (!(W4_ABL & 4)) write_v(raw, (c + 1) & 1);
         if (c == 1) patch_offsets(has_next, nimg, ny0, nx0);
         if (!(W4_ABL & 1)) load_raw(raw, (c + 3) & 3);
-        if (c == 3 && HAS_E) {   // this tile's first epilogue operand, all four rounds
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const int pix = reader_pix(k >> 2, k & 3, img, y0, x0);
-            eop[HAS_E ? k : 0] = bload4(rsE, pix >= 0 ? pix * (e_stride * 4) + e_choff * 4 + (tid & 15) * 16 : OOB, 0);
-          }
-        }
+        // output row c of the PREVIOUS tile's Winograd tiles (pimg < 0: none): exchange plane c -> whole pixels, 16 B per lane
+        drain_plane(c);
         LDS_BARRIER();
       }
+      LDS_BARRIER();   // this tile's results are in the exchange planes
+      pimg = img; py0 = y0; px0 = x0;
+      if (!has_next) {
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        LDS_BARRIER();   // round a of the consumers' results is in the exchange buffer
-        const float* const xb = sX + (a & 1) * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int px = (tid + 256 * i) >> 4, un = tid & 15;
-          const int pix = reader_pix(a, i, img, y0, x0);
-          f32x4 v = *reinterpret_cast<const f32x4*>(xb + px * 64 + ((un ^ ((px >> 2) & 7)) << 2));
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
-          if (MASK) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] *= eop[HAS_E ? 4 * a + i : 0][k] > 0.f ? 1.f : p.mk_slope;
-          } else if (HAS_E) {
-            v += eop[HAS_E ? 4 * a + i : 0];
-          }
-          if (HAS_L) v += bload4(rsL, pix >= 0 ? pix * (l_stride * 4) + l_choff * 4 + un * 16 : OOB, 0);
-          if (!(W4_ABL & 32) || i == 0) bstore4(rsY, pix >= 0 ? pix * (p.y_stride * 4) + p.y_choff * 4 + un * 16 : OOB, v);
-        }
+        for (int a = 0; a < 4; ++a) { drain_request(a, pimg, py0, px0); drain_plane(a); }
+        break;
       }
-      if (!has_next) break;
       tile = next; img = nimg; y0 = ny0; x0 = nx0;
     }
   } else {
@@ -300,14 +308,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       for (int nu = 0; nu < 6; ++nu) at6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu]);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        float* const xb = sX + (a & 1) * 4096;
+        float* const xb = sX + a * 4096;
         at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(xb + xw + b * 64) = acc[6 * a + b];
-        STAMP(8 + a);
-        LDS_BARRIER();
-        STAMP(20 + a);
       }
+      STAMP(8);
+      LDS_BARRIER();   // the tile's results are in the exchange buffer (the producers drain it during the next tile's first chunk)
+      STAMP(20);
       if (!has_next) break;
       tile += 1;
     }

@@ -12,15 +12,15 @@ M = n_img * h * w
 x = torch.randn(M, 64, device="cuda"); wt = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
 wp = capi.pack_conv_weight(wt); y = torch.empty(M, 64, device="cuda"); r = torch.randn(M, 64, device="cuda")
 dbg = torch.zeros(256 * 32 // 4, 4, device="cuda")   # 2-D so the wrapper takes a stride; stride is unused by the DIAG build
-for res in (None, r):
+for res in ((None,) if os.environ.get('LFSR_CONV3X3', '') == '' else (None, r)):
     for _ in range(5):
         capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=res, res2=dbg, out=y)   # R2 carries the debug buffer in the DIAG build
     torch.cuda.synchronize()
     sel = os.environ.get("LFSR_CONV3X3", "")
     if sel == "":   # F(4x4,3x3) kernel (default): per (chunk, stage) segments, chunk barriers, the epilogue at the head of a pass
         d = dbg.reshape(256, 32).cpu().double()
-        names = (["chunk %d MFMA stream" % k for k in range(4)] + ["-"] * 4 + ["epilogue round %d (first: + column pass)" % a for a in range(4)] + ["-"] * 4
-                 + ["barrier after chunk %d" % c for c in range(4)] + ["barrier of round %d" % a for a in range(4)])
+        names = (["chunk %d MFMA stream" % k for k in range(4)] + ["-"] * 4 + ["At M A + exchange writes"] + ["-"] * 7
+                 + ["barrier after chunk %d" % c for c in range(4)] + ["exchange barrier"] + ["-"] * 3)
         tot = d[:, :24].sum(1).mean()
         print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block)")
         for k in range(24):

@@ -16,26 +16,30 @@ def per_kernel(path, counter):
 
 fetch, write, stats, out = sys.argv[1:5]
 F, W = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
-pick = lambda d, key: next((v for k, v in d.items() if key in k), (0.0, 0))
+def pick(d, key):   # launch-weighted mean over every instantiation whose name contains key
+    m = [v for k, v in d.items() if key in k]
+    n = sum(v[1] for v in m)
+    return (sum(v[0] * v[1] for v in m) / n, n) if n else (0.0, 0)
 res = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1`; bytes = "
                  "(2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies the 128-B requests of "
-                 "16-B-per-lane coalesced reads at 64 B); mean over the launches of the kernel "
+                 "16-B-per-lane coalesced reads at 64 B; applied to this kernel's 64-B-run dword reads as well: the L2's fabric requests are the same 128-B lines); mean over the launches of the kernel "
                  "(21 of 53 ops per forward also read a residual operand)"}
 total = 0.0
-for tag, key in (("op", "k_conv3x3_wino<false>"),):
+KEY = "k_conv3x3_wino4<false"   # forward instantiations (<MASK = false, residual operand or not, ...>)
+for tag, key in (("op", KEY),):
     f, n = pick(F, key); w, _ = pick(W, key)
     b = (2.0 * f + w) * 1024.0
     res[tag] = {"kernel": key, "launches": n, "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": b}
     total += b
-res["kernel"] = "k_conv3x3_wino<false>: one launch per 3x3 conv op (256 persistent body blocks over 3072 tiles + 256 channel-split blocks over the 128 leftover tiles)"
+res["kernel"] = "k_conv3x3_wino4<false, *, *>: one launch per 3x3 conv op (256 persistent 512-thread blocks over 3200 tiles of 8 x 32 pixels)"
 res["hbm_bytes_per_launch"] = total
 n_pix = 32 * 25 * 32 * 32
 res["algorithmic_bytes_per_launch"] = n_pix * 256 * (2 + 21.0 / 53.0)   # in + out (+ residual on 21 of 53 ops)
-us = 0.0
+tot_ns, calls = 0.0, 0
 for r in csv.DictReader(open(stats)):
-    if "k_conv3x3_wino<false>" in r["Name"]:
-        us += float(r["AverageNs"]) / 1000.0
-res["rocprof_avg_us_per_op"] = us
+    if KEY in r["Name"]:
+        tot_ns += float(r["TotalDurationNs"]); calls += int(r["Calls"])
+res["rocprof_avg_us_per_op"] = tot_ns / max(calls, 1) / 1000.0
 json.dump(res, open(out, "w"), indent=1)
 if len(sys.argv) > 5:   # optional: every kernel's HBM bytes per launch (same correction) -> profiles/r01_pmc_traffic.json
     allk = {}
