@@ -80,9 +80,10 @@ int lfsr_vcl_to_nchw(const float* in, int in_stride, int in_choff, float* out, i
 /* Pack a PyTorch conv weight (O,C,kh,kw) (device, fp32) into [kh*kw][Npad][C].
  * perm = 0: n' = n.   perm = 1 (PixelShuffle(A) feeding VCL views, DistgSSR.py:87-89): the reference's
  * output channel c*r2 + q becomes n' = q*ch + c (r2 = O/ch views, ch channels per view).
- * A 3x3 64->64 weight (O = C = 64, taps = 9, perm = 0) is followed by its Winograd F(2x2,3x3) copy U = G g G^t
- * (16 x 64 x 64 floats, fragment order of conv3x3_wino.hip); lfsr_packed_weight_floats includes it and
- * lfsr_conv3x3_fwd expects it there. */
+ * A 3x3 64->64 weight (O = C = 64, taps = 9, perm = 0) is followed by its Winograd-domain copies U = G g G^t
+ * (computed in fp64, rounded once): F(2x2,3x3), 16 x 64 x 64 floats in the fragment order of conv3x3_wino.hip, then
+ * F(4x4,3x3), 36 x 64 x 64 floats in the fragment order of conv3x3_wino4.hip (the default kernel);
+ * lfsr_packed_weight_floats includes both and lfsr_conv3x3_fwd expects them there. */
 int lfsr_pack_conv_weight(const float* w, float* packed, int O, int C, int taps, int perm, int ch, void* stream);
 size_t lfsr_packed_weight_floats(int O, int C, int taps);
 
