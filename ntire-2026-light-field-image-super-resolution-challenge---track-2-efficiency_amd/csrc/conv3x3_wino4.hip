@@ -35,6 +35,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef W4_VRING
 #define W4_VRING 4    // depth of the V fragment ring (LDS reads W4_VRING - 1 groups ahead); must divide 36
 #endif
+#ifndef W4_PACE
+#define W4_PACE 0     // producers sleep 64 x W4_PACE cycles between the patch rows of a chunk's loads
+#endif
 #ifndef W4_URING
 #define W4_URING 12   // depth of the U fragment ring (16-B fragments in flight per wave); must divide 144
 #endif
@@ -168,9 +171,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #pragma unroll
       for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(ro[r]));   // the 36 sums are formed here, not kept across the tile
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+      for (int r = 0; r < 6; ++r) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) raw[6 * r + c] = bload1(rsX, ro[r] + co[c], chunk * 64);
+#if W4_PACE
+        // one patch row at a time: the CU's L1 serves the consumers' U stream too, and a burst of 576 line requests (most of them
+        // HBM misses on a tile's first chunks) sits in front of it
+        __builtin_amdgcn_sched_barrier(0);
+        if (r < 5) __builtin_amdgcn_s_sleep(W4_PACE);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
     };
     auto transform = [&](float (&raw)[36]) {
 #pragma unroll
