@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         if (!(W4_ABL & 2)) transform(raw);
         if (!(W4_ABL & 4)) write_v(raw, (c + 1) & 1);
         if (c == 1) patch_offsets(has_next, nimg, ny0, nx0);
-        if (!(W4_ABL & 1)) load_raw(raw, (c + 3) & 3);
+        if (!(W4_ABL & 1) && !((W4_ABL & 64) && c == 3) && !((W4_ABL & 128) && c == 1)) load_raw(raw, (c + 3) & 3);
         // output row c of the PREVIOUS tile's Winograd tiles (pimg < 0: none): exchange plane c -> whole pixels, 16 B per lane
         drain_plane(c);
         LDS_BARRIER();

@@ -52,6 +52,9 @@ def test_conv3x3(B, A, h, w):
     rv = to_vcl(r1, A)
     y2 = capi.conv3x3(to_vcl(x, A), wp, B * A * A, h, w, slope=1.0, res1=rv, res2=rv)
     assert np.abs(from_vcl(y2, B, 64, A, h, w) - ref2).max() < ATOL
+    # a lone residual passed as the SECOND operand (the kernel treats it as its first)
+    y3 = capi.conv3x3(to_vcl(x, A), wp, B * A * A, h, w, slope=1.0, res2=rv)
+    assert np.abs(from_vcl(y3, B, 64, A, h, w) - (ref2 - r1)).max() < ATOL
 
 
 def test_packed_conv_weight_carries_winograd_copy():

@@ -181,3 +181,46 @@ def test_winograd4_restatement_equals_direct_conv():
     U = O.winograd4_weights(w64.astype(np.float64)).reshape(36, 64, 64)
     for (s_, ns, q, ln, e) in [(0, 0, 0, 0, 0), (15, 3, 8, 63, 3), (3, 1, 5, 37, 2), (9, 2, 7, 16, 1)]:
         assert pk[s_, ns, q, ln, e] == np.float32(U[4 * q + e, 16 * ns + ln % 16, 4 * s_ + ln // 16])
+
+
+def test_winograd4_roundoff_through_the_whole_network():
+    """fp32 F(4x4,3x3) in every 3x3 64->64 conv of the DistgSSR forward (53 of them) stays at fp32 round-off of the fp64 direct form --
+    the measurement that cleared the HIP kernel's algorithm before it was written"""
+    import torch
+    import torch.nn.functional as F
+    import oracle.lfsr_torch_port as P
+    from tests.helpers import model_case, psnr
+    case, sd, x, gold = model_case("DistgSSR", "a5h8s4")
+    A, s_ = case["A"], case["s"]
+    BT, AT = torch.from_numpy(O.WINO4_BT).float(), torch.from_numpy(O.WINO4_AT).float()
+
+    def wino4(xv, w):   # xv (N, C, h, w) view images, w (O, C, 3, 3): U in fp64 rounded once, everything else fp32
+        U = torch.from_numpy(O.winograd4_weights(w.double().numpy())).float()
+        N, C, h, wd = xv.shape
+        pat = F.pad(xv, (1, 1, 1, 1)).unfold(2, 6, 4).unfold(3, 6, 4)          # N, C, th, tw, 6, 6
+        V = torch.einsum("ai,ncyxij,bj->abncyx", BT, pat, BT)
+        M = torch.einsum("aboc,abncyx->abnoyx", U, V)
+        return torch.einsum("ia,abnoyx,jb->noyixj", AT, M, AT).reshape(N, U.shape[2], h, wd)
+
+    orig = F.conv2d
+    use = {"on": False}
+
+    def patched(t, w, b=None, stride=1, padding=0, dilation=1, groups=1):
+        if use["on"] and w.shape[1] == 64 and tuple(w.shape[2:]) == (3, 3):
+            v = P.macpi2sai(t, A)
+            B_, C, HH, WW = v.shape
+            h, wd = HH // A, WW // A
+            vv = v.reshape(B_, C, A, h, A, wd).permute(0, 2, 4, 1, 3, 5).reshape(B_ * A * A, C, h, wd)
+            y = wino4(vv, w).reshape(B_, A, A, -1, h, wd).permute(0, 3, 1, 4, 2, 5).reshape(B_, -1, HH, WW)
+            return P.sai2macpi(y, A)
+        return orig(t, w, b, stride, padding, dilation, groups)
+    P.F.conv2d = patched
+    try:
+        sd64 = {k: torch.from_numpy(v).double() for k, v in sd.items()}
+        sd32 = {k: torch.from_numpy(v) for k, v in sd.items()}
+        ref = P.distgssr_forward(torch.from_numpy(x).double(), sd64, A, s_).numpy()
+        use["on"] = True
+        y = P.distgssr_forward(torch.from_numpy(x), sd32, A, s_).double().numpy()
+    finally:
+        P.F.conv2d = orig
+    assert np.abs(y - ref).max() < 1e-5 and psnr(y, ref) > 120.0
