@@ -45,8 +45,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifdef LFSR_CONV_DIAG
 // diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
 #define STAMP(k) do { if (wave == 0) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
+#define PSTAMP(k) do { if (wave == 4) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
+#define PSTAMP(k) do { } while (0)
 #endif
 
 namespace {
@@ -251,15 +253,29 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         // chunk c + 1 (chunk 0 of the next tile when c == 3): transform, V -> the other buffer; then request chunk c + 3 into its registers
         float (&raw)[36] = ((c + 1) & 1) ? raw1 : raw0;
         drain_request(c, pimg, py0, px0);
+#ifdef LFSR_CONV_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (so that segment 24 is the wait for the patch / operand loads)
+#endif
+        PSTAMP(24);
         if (!(W4_ABL & 2)) transform(raw);
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(25);
         if (!(W4_ABL & 4)) write_v(raw, (c + 1) & 1);
         if (c == 1) patch_offsets(has_next, nimg, ny0, nx0);
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(26);
         if (!(W4_ABL & 1) && !((W4_ABL & 64) && c == 3) && !((W4_ABL & 128) && c == 1)) load_raw(raw, (c + 3) & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(27);
         // output row c of the PREVIOUS tile's Winograd tiles (pimg < 0: none): exchange plane c -> whole pixels, 16 B per lane
         drain_plane(c);
+        __builtin_amdgcn_sched_barrier(0);
+        PSTAMP(28);
         LDS_BARRIER();
+        PSTAMP(29);
       }
       LDS_BARRIER();   // this tile's results are in the exchange planes
+      PSTAMP(30);
       pimg = img; py0 = y0; px0 = x0;
       if (!has_next) {
 #pragma unroll
@@ -333,7 +349,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   }
 #ifdef LFSR_CONV_DIAG
   if (dbgbuf && threadIdx.x == 0)
-    for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
+    for (int k = 0; k < 24; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
+  if (dbgbuf && threadIdx.x == 256)
+    for (int k = 24; k < 32; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
 #endif
 }
 

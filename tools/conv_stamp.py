@@ -20,10 +20,11 @@ for res in ((None,) if os.environ.get('LFSR_CONV3X3', '') == '' else (None, r)):
     if sel == "":   # F(4x4,3x3) kernel (default): per (chunk, stage) segments, chunk barriers, the epilogue at the head of a pass
         d = dbg.reshape(256, 32).cpu().double()
         names = (["chunk %d MFMA stream" % k for k in range(4)] + ["-"] * 4 + ["At M A + exchange writes"] + ["-"] * 7
-                 + ["barrier after chunk %d" % c for c in range(4)] + ["exchange barrier"] + ["-"] * 3)
+                 + ["barrier after chunk %d" % c for c in range(4)] + ["exchange barrier"] + ["-"] * 3
+                 + ["P: wait for loads", "P: input transform", "P: V writes (+ offsets)", "P: patch load issue", "P: drain a plane", "P: chunk barrier wait", "P: exchange barrier wait", "-"])
         tot = d[:, :24].sum(1).mean()
         print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block)")
-        for k in range(24):
+        for k in range(32):
             if names[k] == '-': continue
             print(f"   {names[k]:28s} {d[:, k].mean():12.0f} cyc  {100 * d[:, k].mean() / tot:5.1f}%   per tile {d[:, k].mean() / (n_img * 4 / 256):9.0f}")
         continue
