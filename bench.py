@@ -152,10 +152,11 @@ def main():
         y = rt.forward(x)
     torch.cuda.synchronize()
     barrier()
-    # live instrumentation inside the timed region: hipEvents on the launch stream around every 3x3 conv op (the roofline
-    # kernel) and nothing else -- events around all six operator classes cost 0.8 ms per step (tools/prof_overhead.py), around
-    # the convs 0.36 ms; the per-class breakdown comes from a separate, untimed pass below
-    rt.profile(2)
+    # live instrumentation inside the timed region: hipEvents on the launch stream around every 4th 3x3 conv op (the roofline
+    # kernel; 53 ops per forward, so every layer is sampled once in four steps) and nothing else -- events around all six operator
+    # classes cost 0.8 ms per step (tools/prof_overhead.py), around every conv 0.4-0.7 ms; the per-class breakdown comes from a
+    # separate, untimed pass below
+    rt.profile(3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -174,7 +174,7 @@ int lfsr_distgssr_backward(lfsr_distgssr* ctx, const float* x, const float* dout
  * forward (measurement aid for bench.py's roofline line; off by default).
  * classes: 0 conv3x3, 1 angconv, 2 epiconv, 3 pointwise (fuse.0), 4 init_conv, 5 upsample head. */
 #define LFSR_DISTG_NCLASS 6
-int lfsr_distgssr_profile(lfsr_distgssr* ctx, int enable);   /* 0 off, 1 every class, 2 class 0 (3x3 conv) only; drops recorded events */
+int lfsr_distgssr_profile(lfsr_distgssr* ctx, int enable);   /* 0 off, 1 every class, 2 class 0 (3x3 conv) only, 3 every 4th launch of class 0; drops recorded events */
 /* waits for the recorded events, returns summed milliseconds and launch counts per class, then resets */
 int lfsr_distgssr_profile_read(lfsr_distgssr* ctx, double* ms, long long* launches);
 

@@ -33,6 +33,8 @@ struct lfsr_distgssr {
   bool profiling = false;
   struct Ev { int cls; hipEvent_t a, b; };
   bool profile_all = true;
+  int sample_stride = 1;        // profiling mode 3: events around every sample_stride-th 3x3 conv op only
+  long long sample_ctr = 0;
   std::vector<Ev> evs;          // recorded this profiling session
   std::vector<hipEvent_t> free_evs;
   hipEvent_t get_ev() {
@@ -106,7 +108,9 @@ int lfsr_distgssr_profile(lfsr_distgssr* c, int enable) {
   for (auto& e : c->evs) { c->free_evs.push_back(e.a); c->free_evs.push_back(e.b); }
   c->evs.clear();
   c->profiling = enable != 0;
-  c->profile_all = enable != 2;   // enable = 2: events around the 3x3 conv ops only (class 0), the cheapest live measurement
+  c->profile_all = enable == 1;   // enable = 2: events around the 3x3 conv ops only (class 0); 3: around every 4th of them (53 ops per
+  c->sample_stride = enable == 3 ? 4 : 1;   // forward and 4 are coprime: every layer is sampled once in four steps), the cheapest live measurement
+  c->sample_ctr = 0;
   return LFSR_OK;
 }
 
@@ -209,7 +213,7 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
 #define PROF(cls, call)                                                              \
   do {                                                                               \
-    if (c->profiling && (c->profile_all || (cls) == 0)) {                            \
+    if (c->profiling && (c->profile_all || ((cls) == 0 && (c->sample_stride <= 1 || (c->sample_ctr++ % c->sample_stride) == 0)))) { \
       lfsr_distgssr::Ev ev{cls, c->get_ev(), c->get_ev()};                           \
       (void)hipEventRecord(ev.a, lfsr_stream(stream));                                     \
       rc = (call);                                                                   \
