@@ -24,13 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W4_ABL
-#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no patch loads, 2 no input transform, 4 no V writes, 16 no U loads, 32 a quarter of the epilogue stores
-#endif
-#ifndef W4_BPC
-#define W4_BPC 1      // blocks per CU: 2 (<= 256 registers per wave) or 1 (<= 512)
-#endif
-#ifndef W4_SCHED
-#define W4_SCHED 4    // VALU instructions dealt out per MFMA gap (0: leave the stage to the compiler's scheduler)
+#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no patch loads (64 / 128: none in chunk step 3 / 1), 2 no input transform, 4 no V writes,
+                   // 8 every tile loads the same patches (cache hits only), 16 no U loads, 32 a quarter of the epilogue stores
 #endif
 #ifndef W4_VRING
 #define W4_VRING 4    // depth of the V fragment ring (LDS reads W4_VRING - 1 groups ahead); must divide 36
