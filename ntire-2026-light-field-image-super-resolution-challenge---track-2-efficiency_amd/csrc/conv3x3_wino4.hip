@@ -50,10 +50,13 @@ namespace {
 
 constexpr int TS = 584;                 // floats per tile in a V buffer: 16 channels x 36 positions + 8 (2336 B = 32 mod 256)
 constexpr int VBUF = 16 * TS;           // one parity
+#ifndef W4_HALO
+#define W4_HALO 1     // 1: the producers stage a chunk's raw halo through LDS (6 x 16-B loads per thread instead of 36 dword loads)
+#endif
 constexpr int HPIX = 10 * 34;           // raw halo of an 8 x 32 tile
-constexpr int HPS = 20;                 // floats per halo pixel in LDS (16 channels of the chunk + 4: adjacent tiles 16 banks apart)
-constexpr int HBUF = HPIX * HPS;        // one parity
-constexpr int SMEM_BYTES = (2 * VBUF + 4 * 4096) * 4;   // 140288: V, epilogue exchange (one 64-pixel x 64-channel plane per output row of the Winograd tiles)
+constexpr int HBUF = HPIX * 16;         // one 16-channel chunk, 64 B per pixel
+constexpr int SMEM_BYTES = (2 * VBUF + 4 * 4096 + (W4_HALO ? HBUF + 256 : 0)) * 4;   // V, epilogue exchange (one 64-pixel x 64-channel plane per output
+                                                                                      // row of the Winograd tiles), raw halo + 1 KB landing zone: 163072
 constexpr int INV = 1 << 30;            // "outside the image" marker of a row / column offset (operands span < 1 GiB)
 constexpr int OOB = (int)0x80000000u;
 
@@ -108,18 +111,21 @@ __device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, 
 //               and the raw conv result -> the LDS exchange buffer, one output row of every Winograd tile per round.  Their vector
 //               memory queue holds nothing but U loads (L2 hits): vector memory operations return in order, so a single HBM miss or
 //               store burst in that queue holds up every U fragment queued behind it (measured: 5-6k cycles per tile).
-//   waves 4..7  PRODUCERS -- all other global traffic.  Per 16-channel chunk one (Winograd tile, channel) item per thread: 36 dword
-//               loads of its 6x6 patch (16 consecutive lanes = 16 consecutive channels; zero padding and ragged edges are out-of-
-//               range buffer offsets), Bt d B in registers, nine ds_write_b128 into the V buffer of the next chunk; and per chunk
+//   waves 4..7  PRODUCERS -- all other global traffic.  Per 16-channel chunk: the tile's raw halo (340 pixels x 64 B) comes in as six
+//               16-B loads per thread two chunk steps ahead (zero padding and ragged edges are out-of-range buffer offsets) and is
+//               staged in LDS; then one (Winograd tile, channel) item per thread: its 6x6 patch from the staged halo, Bt d B in
+//               registers, nine ds_write_b128 into the V buffer of the next chunk (W4_HALO = 0: 36 dword loads per thread straight
+//               from global memory instead -- 7 % slower: the producers set the pace and vector-memory issue is what they pay most for); and per chunk
 //               one exchange plane of the PREVIOUS tile read back as whole pixels (16 B per lane, 256 B contiguous per pixel),
 //               LeakyReLU / mask / residuals applied, stored.  Their loads miss to HBM and their stores drain while the consumer of the
 //               same SIMD keeps the matrix pipe busy.
-// Barriers per tile: one per chunk (V of the next chunk published, this chunk's V free) + one for the exchange buffer.
+// Barriers per tile: two per chunk (halo staged | V of the next chunk published, this chunk's V free) + one for the exchange buffer.
 template <bool MASK, bool HAS_E, bool HAS_L>
 __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const sV = smem;                 // V[2][16 tiles][16 ch][36]
   float* const sX = smem + 2 * VBUF;      // epilogue exchange: [4 rows a][64 pixels][64 channels]
+  float* const sH = sX + 4 * 4096;        // (W4_HALO) raw halo of one chunk: [340 pixels][16 channels], then the landing zone
   const int tid = threadIdx.x & 255, lane = tid & 63, w4 = (threadIdx.x >> 6) & 3;
   const bool producer = threadIdx.x >= 256;
   const int nblk = gridDim.x;
@@ -231,6 +237,56 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     int img, y0, x0;
     int pimg = -1, py0 = 0, px0 = 0;
     tile_origin(tile, img, y0, x0);
+#if W4_HALO
+    // ---- halo staging: slot i of a thread = (halo pixel, 16-B quarter of the chunk's 64 B) = (idx >> 2, idx & 3), idx = tid + 256 i.
+    // The halo of chunk k waits in hv[k & 1] (requested two chunk steps before its use: a tile's first chunk is the first touch of
+    // its pixels); step k: registers -> LDS, barrier, every thread reads its own 6x6 patch, transform, V.
+    int hx[6];
+    auto halo_offsets = [&](bool valid, int img, int y0, int x0) {
+      if (W4_ABL & 8) { img = blockIdx.x & 7; y0 = 0; x0 = 0; }
+      const int base = (((img * p.H + y0 - 1) * p.W + x0 - 1) * p.x_stride + p.x_choff) * 4;   // wave-uniform
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int px = (tid + 256 * i) >> 2, cq = tid & 3;
+        const int r = __mul24(px, 1928) >> 16;   // px / 34 for px < 384
+        const int c = px - r * 34;
+        const int yy = y0 + r - 1, xx = x0 + c - 1;
+        const bool ok = valid && px < HPIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        hx[i] = ok ? base + __mul24(__mul24(r, p.W) + c, p.x_stride * 4) + cq * 16 : OOB;
+      }
+    };
+    const __amdgpu_buffer_rsrc_t rsXh = make_rsrc(p.X, OOB);
+    f32x4 hv0[6], hv1[6];
+    auto halo_load = [&](f32x4 (&hv)[6], int chunk) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) hv[i] = bload4(rsXh, hx[i], chunk * 64);
+    };
+    auto halo_store = [&](f32x4 (&hv)[6]) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int px = (tid + 256 * i) >> 2, cq = tid & 3;
+        float* dst = (i < 5 || px < HPIX) ? sH + px * 16 + cq * 4 : sH + HBUF + (tid & 63) * 4;   // slots 340..383: landing zone
+        *reinterpret_cast<f32x4*>(dst) = hv[i];
+      }
+    };
+    const float* const hR = sH + ((4 * pty) * 34 + 4 * ptx) * 16 + c16;
+    auto read_raw = [&](float (&raw)[36]) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) raw[6 * r + c] = hR[(r * 34 + c) * 16];
+    };
+    halo_offsets(true, img, y0, x0);
+    halo_load(hv0, 0);
+    halo_load(hv1, 1);
+    halo_store(hv0);
+    LDS_BARRIER();   // (A: halo of chunk 0 staged)
+    read_raw(raw0);
+    halo_load(hv0, 2);
+    transform(raw0);
+    write_v(raw0, 0);
+    LDS_BARRIER();   // (B0)
+#else
     patch_offsets(true, img, y0, x0);
     load_raw(raw0, 0);
     transform(raw0);
@@ -238,6 +294,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     load_raw(raw1, 1);
     load_raw(raw0, 2);
     LDS_BARRIER();   // (B0)
+#endif
     while (true) {
       const int next = tile + 1;
       const bool has_next = next < tile_end;
@@ -246,6 +303,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         // chunk c + 1 (chunk 0 of the next tile when c == 3): transform, V -> the other buffer; then request chunk c + 3 into its registers
+#if W4_HALO
+        {   // chunk c + 1 (chunk 0 of the next tile when c == 3): halo registers -> LDS | patch -> transform -> V of the other parity
+          f32x4 (&hv)[6] = ((c + 1) & 1) ? hv1 : hv0;
+          halo_store(hv);
+          drain_request(c, pimg, py0, px0);
+          LDS_BARRIER();   // (A)
+          read_raw(raw0);
+          if (c == 1) halo_offsets(has_next, nimg, ny0, nx0);   // chunk c + 3 is chunk 0 of the next tile from here on
+          __builtin_amdgcn_sched_barrier(0);
+          if (!(W4_ABL & 1)) halo_load(hv, (c + 3) & 3);
+          if (!(W4_ABL & 2)) transform(raw0);
+          if (!(W4_ABL & 4)) write_v(raw0, (c + 1) & 1);
+          drain_plane(c);
+          LDS_BARRIER();   // (B)
+          continue;
+        }
+#endif
         float (&raw)[36] = ((c + 1) & 1) ? raw1 : raw0;
         drain_request(c, pimg, py0, px0);
 #ifdef LFSR_CONV_DIAG
@@ -292,6 +366,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, uoff, ((i / 9) * 36 + (i % 9)) * 1024);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[36];
+    if (W4_HALO) LDS_BARRIER();   // (A of the prologue)
     LDS_BARRIER();   // (B0)
     STAMP(31);
     while (true) {
@@ -319,6 +394,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
             const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
             if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
             __builtin_amdgcn_sched_barrier(0);       // (keeps every LDS read two groups ahead of its use)
+            if (W4_HALO && g == 3) LDS_BARRIER();    // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
           }
         }
         STAMP(c);
