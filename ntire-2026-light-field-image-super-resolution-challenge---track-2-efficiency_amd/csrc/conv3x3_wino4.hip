@@ -308,15 +308,25 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
           f32x4 (&hv)[6] = ((c + 1) & 1) ? hv1 : hv0;
           halo_store(hv);
           drain_request(c, pimg, py0, px0);
+          __builtin_amdgcn_sched_barrier(0);
+          PSTAMP(24);
           LDS_BARRIER();   // (A)
+          PSTAMP(25);
           read_raw(raw0);
           if (c == 1) halo_offsets(has_next, nimg, ny0, nx0);   // chunk c + 3 is chunk 0 of the next tile from here on
           __builtin_amdgcn_sched_barrier(0);
           if (!(W4_ABL & 1)) halo_load(hv, (c + 3) & 3);
+          __builtin_amdgcn_sched_barrier(0);
+          PSTAMP(26);
           if (!(W4_ABL & 2)) transform(raw0);
           if (!(W4_ABL & 4)) write_v(raw0, (c + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+          PSTAMP(27);
           drain_plane(c);
+          __builtin_amdgcn_sched_barrier(0);
+          PSTAMP(28);
           LDS_BARRIER();   // (B)
+          PSTAMP(29);
           continue;
         }
 #endif

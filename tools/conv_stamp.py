@@ -21,7 +21,7 @@ for res in ((None,) if os.environ.get('LFSR_CONV3X3', '') == '' else (None, r)):
         d = dbg.reshape(256, 32).cpu().double()
         names = (["chunk %d MFMA stream" % k for k in range(4)] + ["-"] * 4 + ["At M A + exchange writes"] + ["-"] * 7
                  + ["barrier after chunk %d" % c for c in range(4)] + ["exchange barrier"] + ["-"] * 3
-                 + ["P: wait for loads", "P: input transform", "P: V writes (+ offsets)", "P: patch load issue", "P: drain a plane", "P: chunk barrier wait", "P: exchange barrier wait", "-"])
+                 + ["P: halo registers -> LDS (+ operand request)", "P: barrier A wait", "P: patch reads + next halo request", "P: input transform + V writes", "P: drain a plane", "P: chunk barrier wait", "P: exchange barrier wait", "-"])
         tot = d[:, :24].sum(1).mean()
         print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block)")
         for k in range(32):
