@@ -36,6 +36,7 @@ def from_vcl(v, B, C, A, h, w, choff=0):
 
 
 GEOMS = [(1, 5, 8, 8), (2, 3, 6, 8), (1, 5, 32, 32), (3, 2, 5, 7)]
+WIDE_GEOMS = [(1, 2, 20, 40), (2, 1, 37, 70)]   # view images wider than one 32-column tile, ragged in both directions
 
 
 @pytest.mark.parametrize("B,A,h,w", GEOMS)
@@ -55,6 +56,24 @@ def test_conv3x3(B, A, h, w):
     # a lone residual passed as the SECOND operand (the kernel treats it as its first)
     y3 = capi.conv3x3(to_vcl(x, A), wp, B * A * A, h, w, slope=1.0, res2=rv)
     assert np.abs(from_vcl(y3, B, 64, A, h, w) - (ref2 - r1)).max() < ATOL
+
+
+@pytest.mark.parametrize("B,A,h,w", WIDE_GEOMS)
+def test_conv3x3_wide_views(B, A, h, w, monkeypatch):
+    """several tile columns per view image (the persistent kernels walk contiguous tile ranges across them), all kernel selections"""
+    x = rnd((B, 64, A * h, A * w), 31)
+    wt = rnd((64, 64, 3, 3), 32, 0.05)
+    r1 = rnd((B, 64, A * h, A * w), 33)
+    ref = O.leaky_relu(O.conv2d(x.astype(np.float64), wt.astype(np.float64), dilation=(A, A), padding=(A, A)), 0.1) + r1
+    wp = capi.pack_conv_weight(dev(wt))
+    xv, rv = to_vcl(x, A), to_vcl(r1, A)
+    for sel in ("", "wino2", "halo"):
+        if sel: monkeypatch.setenv("LFSR_CONV3X3", sel)
+        else: monkeypatch.delenv("LFSR_CONV3X3", raising=False)
+        y = capi.conv3x3(xv, wp, B * A * A, h, w, slope=0.1, res1=rv)
+        torch.cuda.synchronize()
+        assert np.abs(from_vcl(y, B, 64, A, h, w) - ref).max() < ATOL, sel
+    monkeypatch.delenv("LFSR_CONV3X3", raising=False)
 
 
 def test_packed_conv_weight_carries_winograd_copy():
