@@ -1,22 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- the headline measurement (BASELINE.json: 5x5 x4-SR LF patches/sec, 32^2 -> 128^2).
 
-Workload at every N: configs[1] "DistgSSR 5x5 x4 inference, batch 32 patches" per GPU; a step is one
-forward of the HIP path over one batch of 32 synthetic patches already resident in HBM.  N > 1: one
-process per GPU (torchrun env), patches are independent so ranks share no data-path collective
-("weak" scaling: 32 patches per GPU); RCCL is used only for the barrier and the max-over-ranks clock.
+Workload at every N (default): configs[1] "DistgSSR 5x5 x4 inference, batch 32 patches" per GPU; a step is one forward of the
+HIP path over one batch of 32 synthetic patches already resident in HBM.  N > 1: one process per GPU; patches are independent
+so ranks share no data-path collective ("weak" scaling: 32 patches per GPU); RCCL carries only the barrier and the
+max-over-ranks clock.  Other workloads (`--workload train|epit|lft`) are configs[3], [2], [4] on the same harness.
 
-One JSON line on rank 0.  `roofline` is for the dominant kernel (the per-view 3x3 64->64 conv, 77 % of
-DistgSSR FLOPs, MFMA-bound in fp32): algorithmic FLOPs per launch = 2 * 576 * 64 * (B*25*32*32) (SURVEY 8d:
-direct-conv 2 x MAC) divided by that op's average duration, measured with hipEvents recorded on the launch
-stream around every launch inside the timed region.  The op runs in Winograd F(2x2,3x3) form, which issues
-2.25x fewer MFMA flops than that count -- `achieved`/`peak` can therefore exceed 1; `mfma_util` is the physical
-matrix-pipe utilisation (flops actually issued / time / peak).  `cpu_baseline` = the numpy oracle (fp32 mode)
-timed on this box's host cores on a bounded sample (rank 0, N = 1 only).
+Launch forms (both give the same ranks):
+  * `python bench.py --gpus N ...`                       -- the parent spawns its N ranks itself as FRESH child processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment) before it has imported
+    torch or touched the GPU, relays rank 0's JSON line and exits with the worst child status;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`   -- torchrun provides the environment.
+
+One JSON line on rank 0.
+  roofline          the dominant kernel (per-view 3x3 64->64 conv, 77 % of DistgSSR FLOPs, fp32-MFMA-bound): `achieved` = the
+                    flops the op EXECUTES on the matrix pipe per launch (Winograd F(4x4,3x3): 36 position-GEMMs of
+                    [16 tiles x 64] x [64 x 64] per 8x32-pixel tile = 2.25/9 of the direct 2 x 576 x 64 x pixels of SURVEY 8d)
+                    / that op's average duration, measured with hipEvents on the launch stream inside the timed region;
+                    `frac` = max(MFMA floor, HBM floor) / duration on that executed work -- a true roofline fraction (< 1).
+                    The direct-conv-equivalent rate and the algorithmic speed-up over a direct conv are separate fields.
+  roofline_classes  one line per other kernel class of the forward (and the stand-alone SAI<->MacPI / PixelShuffle kernels),
+                    algorithmic bytes or flops / hipEvent time, against 8 TB/s (and the 6.3 TB/s a float4 copy reaches) or the
+                    fp32 MFMA peak; taken in a separate untimed pass (events around every class cost ~0.8 ms per step).
+  cpu_baseline      SURVEY 8d: oracle/lfsr_torch_port.py (stock torch CPU ops = what the reference's CPU path runs), fp32,
+                    B = 4 chunks, thread count = a short sweep around the physical cores this process may use; plus one line
+                    each for configs 1, 3, 5 (rank 0, N = 1 only; bounded to ~30-40 s).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,28 +38,176 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 A, H, W, S, BATCH = 5, 32, 32, 4, 32
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-FLOP_PER_PATCH = 130.525e9      # SURVEY 8d, DistgSSR x4 forward, 2 x MAC
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+HBM_PEAK_TBPS = 8.0             # MI355X_MICROARCH.md: HBM3E spec; 6.29 TB/s is what a float4 copy reaches
+HBM_COPY_TBPS = 6.29
+FLOP_PER_PATCH = {"distgssr": 130.525e9, "epit": 148.9e9, "lft": 62.4e9}   # SURVEY 8d (EPIT / LFT: windowed accounting -- the kernels visit valid keys only)
 
 
-def cpu_baseline(sd, x1):
-    """The oracle's torch-CPU form (stock ATen ops == what the reference's CPU path runs), fp32,
-    one patch of the same geometry per call, bounded to ~10-20 s of CPU work."""
-    import torch
-    from oracle import lfsr_torch_port as T
-    threads = torch.get_num_threads()
-    sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
-    xt = torch.from_numpy(x1)
-    T.distgssr_forward(xt, sdt, A, S)   # warm-up
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: 32 infer, 8 train / epit / lft)")
+    ap.add_argument("--workload", choices=["infer", "train", "epit", "lft"], default="infer",
+                    help="infer = configs[1] (headline, default); train = configs[3]: DistgSSR x4 fp32 train step, batch 8 per GPU, RCCL bucket "
+                         "all-reduce; epit = configs[2]; lft = configs[4] (full scene through LFdivide / LFintegrate, patches sharded)")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# parent: spawn the ranks (no torch, no GPU in this process)
+# ------------------------------------------------------------------------------------------------------------------
+
+def launch_ranks(args):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------------------------
+
+def physical_cores():
+    """Physical cores this process may run on: unique (package, core) pairs of /proc/cpuinfo restricted to the affinity mask."""
+    allowed = os.sched_getaffinity(0)
+    cores, cur, phys, core = set(), None, 0, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cur = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+                if cur in allowed:
+                    cores.add((phys, core))
+    except OSError:
+        pass
+    return max(1, len(cores) if cores else len(allowed)), len(allowed)
+
+
+def _time_cpu(fn, budget_s, max_iter):
+    fn()   # warm-up
     n, t0 = 0, time.perf_counter()
     while True:
-        T.distgssr_forward(xt, sdt, A, S)
+        fn()
         n += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or n >= 40:
-            break
-    return {"value": n / el, "unit": "patches/s", "cores": threads, "kind": "port",
-            "sample": f"{n} x 1 patch (5x5 views of 32x32, x4) through oracle/lfsr_torch_port.py (stock torch CPU ops, fp32), {el:.1f} s"}
+        if el > budget_s or n >= max_iter:
+            return n, el
+
+
+def cpu_baseline(sd_np, x_np):
+    import numpy as np
+    import torch
+    from oracle import lfsr_torch_port as T
+    from lfsr_amd.synth import synth_input, synth_state_dict
+    phys, logical = physical_cores()
+    sdt = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    x4 = torch.from_numpy(np.ascontiguousarray(x_np[:4]))
+    sweep = []
+    cands = sorted({max(1, phys // 2), phys, min(logical, 2 * phys)})
+    for nt in cands:
+        torch.set_num_threads(nt)
+        n, el = _time_cpu(lambda: T.distgssr_forward(x4, sdt, A, S), 4.0, 3)
+        sweep.append({"threads": nt, "patches_per_s": 4 * n / el, "iters": n})
+    best = max(sweep, key=lambda r: r["patches_per_s"])
+    torch.set_num_threads(best["threads"])
+    meta_all = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"]
+    others = []
+    for cfg, name, fn, s, flop in (("configs[0]: LF_InterNet 5x5 x2, one 32x32 patch", "LF_InterNet", T.internet_forward, 2, 84.653e9),
+                                   ("configs[2]: EPIT 5x5 x4, B = 1", "EPIT", T.epit_forward, 4, 162.611e9),
+                                   ("configs[4]: LFT 5x5 x4, B = 1 patch of the LFdivide list", "LFT", T.lft_forward, 4, 114.797e9)):
+        spec = meta_all[name]["full"]["spec"]
+        sdo = {k: torch.from_numpy(v) for k, v in synth_state_dict([(k, tuple(sh)) for k, sh in spec], seed=0).items()}
+        xo = torch.from_numpy(synth_input((1, 1, A * H, A * W), seed=1))
+        n, el = _time_cpu(lambda: fn(xo, sdo, A, s), 3.0, 3)
+        others.append({"config": cfg, "value": n / el, "unit": "patches/s", "threads": best["threads"],
+                       "sample": f"{n} x 1 patch through oracle/lfsr_torch_port.py:{fn.__name__}, {el:.1f} s", "reference_dense_gflop_per_patch": flop / 1e9})
+    return {"value": best["patches_per_s"], "unit": "patches/s", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['iters']} x 4 patches (B = 4 chunks of the B = 32 batch; 5x5 views of 32x32, x4) through "
+                      "oracle/lfsr_torch_port.py:distgssr_forward (stock torch CPU ops, fp32)",
+            "physical_cores_available": phys, "logical_cpus_available": logical, "thread_sweep": sweep, "other_configs": others}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# rank body
+# ------------------------------------------------------------------------------------------------------------------
+
+def init_rank(args):
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL
+    if os.environ.get("LFSR_BENCH_ONE_DEVICE"):
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("LFSR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    return rank, world, dev, dist
+
+
+def timed_loop(step, args, dev, dist):
+    """W warm-ups, then exactly K steps bracketed by barrier + synchronize; returns the max-over-ranks seconds and the last result."""
+    import torch
+    r = None
+    for _ in range(args.warmup):
+        r = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el, r
+
+
+def finish(dist):
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def base_line(args, world, el, patches_per_step, metric, workload, extra_cfg):
+    return {"metric": metric, "value": world * patches_per_step * args.steps / el, "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": dict({"workload": workload, "batch_per_gpu": patches_per_step}, **extra_cfg)}
 
 
 def bench_train(args, rank, world, dev, dist):
@@ -60,7 +222,7 @@ def bench_train(args, rank, world, dev, dist):
     sys.path.insert(0, capi._HERE)
     M = importlib.import_module("model.SR.DistgSSR")
     sys.path.remove(capi._HERE)
-    Bt = 8
+    Bt = args.batch or 8
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"]["DistgSSR"]["full"]
     sd = synth_state_dict([(k, tuple(s)) for k, s in meta["spec"]], seed=0)
     net = M.get_model(Namespace(angRes_in=A, angRes_out=A, scale_factor=S))
@@ -71,99 +233,99 @@ def bench_train(args, rank, world, dev, dist):
     opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
     x = torch.from_numpy(synth_input((Bt, 1, A * H, A * W), seed=1 + rank)).to(dev)
     y = torch.from_numpy(synth_input((Bt, 1, A * H * S, A * W * S), seed=100 + rank)).to(dev)
-    for _ in range(args.warmup):
-        train_step(net, crit, opt, x, y)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = train_step(net, crit, opt, x, y)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    el, (loss, _) = timed_loop(lambda: train_step(net, crit, opt, x, y), args, dev, dist)
     if rank == 0:
-        print(json.dumps({
-            "metric": "5x5 x4-SR LF patches/sec (32^2->128^2), DistgSSR training step (fwd+bwd+allreduce+AdamW)",
-            "value": world * Bt * args.steps / el, "unit": "patches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "loss": float(loss),
-            "config": {"workload": "configs[3]: DistgSSR 5x5 x4 training, batch 8 per GPU, data-parallel, one RCCL all-reduce of the flat gradient bucket",
-                       "batch_per_gpu": Bt, "parallelism": f"dp{world}"},
-            "model_tflops": 3 * FLOP_PER_PATCH * world * Bt * args.steps / el / 1e12}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        line = base_line(args, world, el, Bt, "5x5 x4-SR LF patches/sec (32^2->128^2), DistgSSR training step (fwd+bwd+allreduce+AdamW)",
+                         "configs[3]: DistgSSR 5x5 x4 training, batch 8 per GPU, data-parallel, one RCCL all-reduce of the flat gradient bucket",
+                         {"parallelism": f"dp{world}"})
+        line["loss"] = float(loss)
+        line["model_tflops"] = 3 * FLOP_PER_PATCH["distgssr"] * world * Bt * args.steps / el / 1e12
+        print(json.dumps(line), flush=True)
+    finish(dist)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["infer", "train"], default="infer",
-                    help="infer = configs[1] (headline, default); train = configs[3]: DistgSSR x4 fp32 train step, batch 8 per GPU, RCCL bucket all-reduce")
-    args = ap.parse_args()
+def bench_model(args, rank, world, dev, dist):
+    """configs[2] (EPIT, a batch of patches per GPU) / configs[4] (LFT, one full scene per step: LFdivide -> sharded batched forward ->
+    all-gather -> LFintegrate; every rank holds the scene, as the reference's test() does)."""
+    import torch
+    from lfsr_amd import capi
+    from lfsr_amd.synth import synth_input, synth_state_dict
+    name = args.workload
+    key = {"epit": "EPIT", "lft": "LFT"}[name]
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"][key]["full"]
+    sd = synth_state_dict([(k, tuple(s)) for k, s in meta["spec"]], seed=0)
+    rt = capi.ModelRuntime(name, A, S, 5 if name == "epit" else 4, 64)
+    rt.load_state([(k, torch.from_numpy(v).to(dev)) for k, v in sd.items()], dev)
+    if name == "epit":
+        Bm = args.batch or 8
+        x = torch.from_numpy(synth_input((Bm, 1, A * H, A * W), seed=1 + rank)).to(dev)
+        el, y = timed_loop(lambda: rt.forward(x), args, dev, dist)
+        per_step, wl = Bm, f"configs[2]: EPIT 5x5 x4 inference, batch {Bm} patches per GPU"
+        par = f"patch-sharded x{world}, no data-path collective"
+    else:
+        from lfsr_amd.dispatch import sr_scene
+        scene = torch.from_numpy(synth_input((A * 128, A * 128), seed=3)).to(dev)      # 5x5x128x128 -> 64 patches -> (5,5,512,512)
+        el, y = timed_loop(lambda: sr_scene(lambda t, info=None: rt.forward(t), scene, A, S, minibatch=args.batch or 32), args, dev, dist)
+        per_step, wl = 64.0 / world, "configs[4]: LFT 5x5 x4 full-scene inference (5x5x128x128 -> 64 patches via LFdivide / LFintegrate)"
+        par = f"64 patches sharded over {world} rank(s), one all-gather of the SR patches"
+    if rank == 0:
+        assert torch.isfinite(y).all()
+        line = base_line(args, world, el, per_step, f"5x5 x4-SR LF patches/sec (32^2->128^2), {key} inference", wl, {"parallelism": par})
+        if name == "lft":
+            line["scaling"] = "strong"
+        line["model_tflops_windowed"] = FLOP_PER_PATCH[name] * line["value"] / 1e12
+        print(json.dumps(line), flush=True)
+    finish(dist)
 
+
+def index_micro(dev):
+    """stand-alone a1 / a2 / a3 at the bench geometry (B = 32, C = 64): algorithmic bytes = one read + one write of every element."""
+    import torch
+    from lfsr_amd import capi
+    out = []
+
+    def t_us(fn, n=10):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+    x = torch.rand(BATCH, 64, A * H, A * W, device=dev)
+    p = torch.rand(2, 64 * S * S, A * H, A * W, device=dev)
+    for cls, kern, nbytes, fn in (
+            ("a1 SAI2MacPI (32,64,160,160)", "k_sai_macpi", 2 * x.numel() * 4, lambda: capi.sai2macpi(x, A)),
+            ("a2 MacPI2SAI (32,64,160,160)", "k_sai_macpi", 2 * x.numel() * 4, lambda: capi.macpi2sai(x, A)),
+            ("a3 PixelShuffle(4) (2,1024,160,160)", "k_pixel_shuffle2d", 2 * p.numel() * 4, lambda: capi.pixel_shuffle2d(p, S)),
+            ("float4 copy of the a1 bytes (reference point: torch clone)", "copy", 2 * x.numel() * 4, lambda: x.clone())):
+        us = t_us(fn)
+        out.append({"class": cls, "kernel": kern, "bound": "hbm", "bytes": nbytes, "us": us, "achieved": nbytes / us / 1e6, "unit": "TB/s",
+                    "frac": nbytes / us / 1e6 / HBM_PEAK_TBPS, "frac_of_copy": nbytes / us / 1e6 / HBM_COPY_TBPS})
+    return out
+
+
+def bench_infer(args, rank, world, dev, dist):
     import numpy as np
     import torch
     from lfsr_amd import capi
     from lfsr_amd.synth import synth_input, synth_state_dict
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on device 0, gloo instead of RCCL
-    if os.environ.get("LFSR_BENCH_ONE_DEVICE"):
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        backend = os.environ.get("LFSR_BENCH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    if args.workload == "train":
-        return bench_train(args, rank, world, dev, dist)
+    B = args.batch or BATCH
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"]["DistgSSR"]["full"]
     sd = synth_state_dict([(k, tuple(s)) for k, s in meta["spec"]], seed=0)
     rt = capi.DistgSSRRuntime(A, S)
     rt.load_state([(k, torch.from_numpy(v).to(dev)) for k, v in sd.items()], dev)
-    x_np = synth_input((BATCH, 1, A * H, A * W), seed=1 + rank)          # each rank its own shard of patches
+    x_np = synth_input((B, 1, A * H, A * W), seed=1 + rank)          # each rank its own shard of patches
     x = torch.from_numpy(x_np).to(dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
     for _ in range(args.warmup):
-        y = rt.forward(x)
-    torch.cuda.synchronize()
-    barrier()
+        rt.forward(x)
     # live instrumentation inside the timed region: hipEvents on the launch stream around every 4th 3x3 conv op (the roofline
-    # kernel; 53 ops per forward, so every layer is sampled once in four steps) and nothing else -- events around all six operator
-    # classes cost 0.8 ms per step (tools/prof_overhead.py), around every conv 0.4-0.7 ms; the per-class breakdown comes from a
-    # separate, untimed pass below
+    # kernel; 53 ops per forward, so every layer is sampled once in four steps) and nothing else
     rt.profile(3)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = rt.forward(x)
-    torch.cuda.synchronize()
-    barrier()
-    el = time.perf_counter() - t0
+    el, y = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
     prof = rt.profile_read()
     rt.profile(1)
     nb = 3
@@ -172,61 +334,89 @@ def main():
     torch.cuda.synchronize()
     prof_all = rt.profile_read()
     rt.profile(0)
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-
     if rank == 0:
         assert torch.isfinite(y).all()
+        # B = 32 forward == the same patches run one at a time (batch independence of the path; bit-equal expected)
+        y1 = torch.cat([rt.forward(x[i:i + 1]) for i in (0, B - 1)], 0)
+        batch_split_max_abs_diff = float((y1 - rt.forward(x)[[0, B - 1]]).abs().max())
+        M = B * A * A * H * W
         conv_ms, conv_n = prof["conv3x3"]
-        conv_avg_ms = conv_ms / max(conv_n, 1)
-        M = BATCH * A * A * H * W
-        conv_flop = 2.0 * 576 * 64 * M
-        ach = conv_flop / (conv_avg_ms * 1e-3) / 1e12
+        conv_s = conv_ms / max(conv_n, 1) * 1e-3
+        direct_flop = 2.0 * 576 * 64 * M
         sel = os.environ.get("LFSR_CONV3X3", "")
-        direct = sel[:1] in ("h", "g")
-        wino2 = sel[:5] == "wino2"
-        # flops the MFMA pipe actually executes per op: per 8 x 32-pixel tile F(4x4,3x3) runs 36 position-GEMMs of 16 tiles x 64 x 64
-        # (2.25 multiplies per output and channel pair), F(2x2,3x3) 16 of 64 tiles x 64 x 64 (4), the direct form 9 taps (9)
-        exec_flop = conv_flop if direct else conv_flop * (4.0 / 9.0 if wino2 else 2.25 / 9.0)
-        kname = ("k_conv3x3_halo (direct 9-tap halo-tile kernel + channel-split tail launch)" if direct else
-                 "k_conv3x3_wino (Winograd F(2x2,3x3): persistent 8x32 tiles, 16 position-GEMMs on fp32 MFMA 32x32x2, in-place halo streaming)" if wino2 else
-                 "k_conv3x3_wino4 (per-view 3x3 64->64 in Winograd F(4x4,3x3) form: persistent 8x32-pixel tiles, 36 position-GEMMs on fp32 MFMA "
-                 "16x16x4 with the inverse transform in registers; 4 MFMA consumer waves + 4 producer waves per CU, V through LDS, U streamed from L2)")
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_conv3x3.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        line = {
-            "metric": "5x5 x4-SR LF patches/sec (32^2->128^2), DistgSSR inference",
-            "value": world * BATCH * args.steps / el,
-            "unit": "patches/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: DistgSSR 5x5 x4 inference, batch 32 patches per GPU (5x5 views of 32x32 -> 128x128)",
-                       "batch_per_gpu": BATCH, "parallelism": f"patch-sharded x{world}, no data-path collective",
-                       "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": kname + "; duration = one conv op",
-                         "flop_per_launch": conv_flop, "executed_flop_per_launch": exec_flop,
-                         "mfma_util": exec_flop / (conv_avg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                         "note": "achieved = algorithmic direct-conv flops (SURVEY 8d) / time; the Winograd F(4x4,3x3) form issues 4x fewer MFMA "
-                                 "flops (F(2x2,3x3): 2.25x), so frac may exceed 1 -- mfma_util is the matrix-pipe utilisation",
-                         "avg_launch_ms": conv_avg_ms, "launches_timed": conv_n},
-            "model_tflops": FLOP_PER_PATCH * world * BATCH * args.steps / el / 1e12,
-            "kernel_ms_per_step": {k: v[0] / nb for k, v in prof_all.items()},
-            "kernel_ms_per_step_note": f"separate untimed pass of {nb} steps with events around every operator class",
+        direct, wino2 = sel[:1] in ("h", "g"), sel[:5] == "wino2"
+        exec_flop = direct_flop * (1.0 if direct else 4.0 / 9.0 if wino2 else 2.25 / 9.0)
+        conv_bytes = (2 + 21.0 / 53.0) * M * 64 * 4            # in + out per launch, + the residual operand on 21 of the 53 ops
+        mfma_floor, hbm_floor = exec_flop / (FP32_MFMA_PEAK_TFLOPS * 1e12), conv_bytes / (HBM_PEAK_TBPS * 1e12)
+        kname = ("k_conv3x3_halo (direct 9-tap halo-tile kernel)" if direct else
+                 "k_conv3x3_wino (Winograd F(2x2,3x3), 16 position-GEMMs on fp32 MFMA 32x32x2)" if wino2 else
+                 "k_conv3x3_wino4 (per-view 3x3 64->64 in Winograd F(4x4,3x3) form: 36 position-GEMMs per 8x32-pixel tile on fp32 MFMA 16x16x4)")
+        traffic, tsrc = None, None
+        for cand in ("r02_pmc_traffic.json", "pmc_conv3x3.json"):
+            pmc = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pmc):
+                j = json.load(open(pmc))
+                traffic = j.get("conv3x3", j).get("hbm_bytes_per_launch")
+                tsrc = f"profiles/{cand}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH_SIZE x 2 (gfx950 correction); not re-measured in this run"
+                break
+        line = base_line(args, world, el, B, "5x5 x4-SR LF patches/sec (32^2->128^2), DistgSSR inference",
+                         f"configs[1]: DistgSSR 5x5 x4 inference, batch {B} patches per GPU (5x5 views of 32x32 -> 128x128)",
+                         {"parallelism": f"patch-sharded x{world}, no data-path collective",
+                          "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"})
+        line["roofline"] = {
+            "bound": "mfma", "achieved": exec_flop / conv_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": max(mfma_floor, hbm_floor) / conv_s, "traffic": traffic, "traffic_source": tsrc,
+            "kernel": kname + "; duration = one conv op", "executed_flop_per_launch": exec_flop, "algorithmic_bytes_per_launch": conv_bytes,
+            "mfma_floor_us": mfma_floor * 1e6, "hbm_floor_us": hbm_floor * 1e6, "avg_launch_us": conv_s * 1e6, "launches_timed": conv_n,
+            "direct_conv_flop_per_launch": direct_flop, "direct_equivalent_tflops": direct_flop / conv_s / 1e12,
+            "algorithmic_speedup_over_direct_form": direct_flop / exec_flop,
+            "note": "frac is on the work the kernel executes (Winograd domain), so it is a true fraction; direct_equivalent_tflops = SURVEY 8d's "
+                    "2 x 576 x 64 x pixels / time may exceed the peak and is not a roofline figure"}
+        # per-class lines: algorithmic bytes (one read of every input + one write of every output, fp32) and flops per launch at this B
+        npx = float(M)
+        cls_spec = {   # class -> (kernel, bound, bytes, flop)
+            "epiconv": ("k_epi (both EPI passes: 1xA^2 conv 64->32, LReLU, 1x1 32->160, LReLU, PixelShuffle1D; DistgSSR.py:91-97,108)", "mfma",
+                        (64 + 64) * npx * 4, 2 * (16.78e9 + 1.68e9) * B),
+            "pointwise": ("fuse.0 144->64 + LReLU (DistgSSR.py:98-100,109)", "hbm", (144 + 64) * npx * 4, 0.472e9 * 16 / 16 * B),
+            "angconv": ("k_ang_fused (AngConv.0 + LReLU + AngConv.2 + LReLU + PixelShuffle(A); DistgSSR.py:84-90)", "hbm", (64 + 16) * npx * 4, 0.065e9 * B),
+            "init_conv": ("k_initconv (SAI2MacPI + 3x3 1->64; DistgSSR.py:22,31-32)", "hbm", (1 + 64) * npx * 4, 0.029e9 * B),
+            "upsample_head": ("k_head<4> (MacPI2SAI + folded 64->16 1x1 + PixelShuffle(4) + bilinear skip; DistgSSR.py:24-35)", "hbm",
+                              (64 + 1 + 16) * npx * 4, 2.0 * 64 * 16 * npx),
         }
+        classes = []
+        for cls, (kern, bound, nbytes, flop) in cls_spec.items():
+            ms, n = prof_all[cls]
+            if not n:
+                continue
+            us = ms / n * 1e3
+            e = {"class": cls, "kernel": kern, "bound": bound, "launches_per_step": n // nb, "bytes": nbytes, "flop": flop, "us": us,
+                 "TBps": nbytes / us / 1e6, "TFLOPs": flop / us / 1e6}
+            if bound == "hbm":
+                e.update(achieved=e["TBps"], unit="TB/s", frac=e["TBps"] / HBM_PEAK_TBPS, frac_of_copy=e["TBps"] / HBM_COPY_TBPS)
+            else:
+                e.update(achieved=e["TFLOPs"], unit="TFLOP/s", frac=e["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS)
+            classes.append(e)
+        line["roofline_classes"] = classes + index_micro(dev)
+        line["model_tflops"] = FLOP_PER_PATCH["distgssr"] * line["value"] / 1e12
+        line["kernel_ms_per_step"] = {k: v[0] / nb for k, v in prof_all.items()}
+        line["kernel_ms_per_step_note"] = f"separate untimed pass of {nb} steps with events around every operator class"
+        line["batch_split_max_abs_diff"] = batch_split_max_abs_diff
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, x_np[:1])
+            line["cpu_baseline"] = cpu_baseline(sd, x_np)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(dist)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))     # before torch is imported or anything touches the GPU
+    rank, world, dev, dist = init_rank(args)
+    if args.workload == "train":
+        return bench_train(args, rank, world, dev, dist)
+    if args.workload in ("epit", "lft"):
+        return bench_model(args, rank, world, dev, dist)
+    return bench_infer(args, rank, world, dev, dist)
 
 
 if __name__ == "__main__":

@@ -251,6 +251,9 @@ int lfsr_view_metrics(const float* label, const float* out, double* psnr, double
 /* N3: MaskedAngularPretraining.forward, utils/masked_pretraining.py:85-139: y = x with the views flagged in mask[A*A]
  * (device bytes) filled with `fill` ('zero' / 'mean' strategies; the reference applies one mask to the whole batch). */
 int lfsr_mask_views(const float* x, float* y, const unsigned char* mask, float fill, int B, int C, int A, int h, int w, void* stream);
+/* the same with one fill value per view, fill[A*A] device floats (mask_value 'mean' with several masked views: each view is filled with
+ * its OWN mean over batch, channels and pixels, masked_pretraining.py:121-123) */
+int lfsr_mask_views_fill(const float* x, float* y, const unsigned char* mask, const float* fill, int B, int C, int A, int h, int w, void* stream);
 
 /* N4, output tail of test() (train.py:329-341, inference.py:205-216; utils/utils.py:191-204 ycbcr2rgb):
  * out[(u, v, y, x, c)] = uint8(clip(M255 . (Y, Cb, Cr) - offset, 0, 1) * 255), evaluated in fp64 like the reference's numpy path.

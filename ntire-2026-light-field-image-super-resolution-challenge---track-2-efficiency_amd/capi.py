@@ -58,6 +58,7 @@ SIGNATURES = {
     "lfsr_lft_position_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_view_metrics": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_mask_views": (c_i, [c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_mask_views_fill": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_internet_create": (c_i, [C.POINTER(c_p), c_i, c_i, c_i, c_i]),
     "lfsr_internet_destroy": (None, [c_p]),
     "lfsr_internet_packed_bytes": (c_sz, [c_p]),
@@ -268,6 +269,7 @@ class DistgSSRRuntime:
         self.packed = None
         self.ws = {}
         self.loaded_version = None
+        self.train_generation = 0     # bumped by every forward_train: identifies whose activations the training workspace holds
 
     def __del__(self):
         try:
@@ -327,6 +329,7 @@ class DistgSSRRuntime:
         ws = self._train_workspace(B, h, w, x.device)
         check(self.lib.lfsr_distgssr_forward_train(self.ctx, dev_ptr(x), dev_ptr(out), B, h, w, dev_ptr(ws), ws.numel(), stream_ptr()),
               "distgssr_forward_train")
+        self.train_generation += 1
         return out
 
     def backward(self, x, dout, grads=None):

@@ -152,7 +152,7 @@ bool lfsr_ang_fused_ok(int A) { return A >= 1 && A <= 5 && lfsr_ang_fused_smem(A
 int lfsr_ang_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* t, float* y,
                           int y_stride, int y_choff, int B, int A, int h, int w, float slope, hipStream_t st) {
   if (!lfsr_ang_fused_ok(A)) return LFSR_E_ARG;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {

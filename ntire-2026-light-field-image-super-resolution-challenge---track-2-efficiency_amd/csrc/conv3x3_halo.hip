@@ -43,6 +43,7 @@ struct ConvArgs {
   int n_img, H, W, tiles_y, tiles_x;
   int tile_begin, tile_count;   // tiles [tile_begin, tile_begin + tile_count) belong to this launch
   float slope;
+  float* dbg;                   // (LFSR_CONV_DIAG builds: stamp buffer; else unused)
 };
 
 // MASK = false: forward / plain dgrad (optional residuals R1, R2).  MASK = true: dgrad through a LeakyReLU, the operand
@@ -96,8 +97,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs p) {
 #ifdef LFSR_CONV_DIAG
   long long seg[6] = {0, 0, 0, 0, 0, 0};
   long long tprev = clock64();
-  float* dbgbuf = const_cast<float*>(p.R2);
-  p.R2 = nullptr;
+  float* dbgbuf = p.dbg;
 #endif
   int tile = p.tile_begin + (NHALF ? (int)(blockIdx.x >> 1) : (int)blockIdx.x);
   int img, y0, x0;
@@ -283,7 +283,7 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
                              int n_img, int h, int w, float slope, hipStream_t st) {
-  static bool attr_set[64] = {};   // per device: the >64 KB dynamic-LDS opt-in is a per-device function attribute
+  static std::atomic<bool> attr_set[64];   // per device: the >64 KB dynamic-LDS opt-in is a per-device function attribute
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
@@ -300,11 +300,14 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
   p.R1 = r1; p.r1_stride = r1_stride; p.r1_choff = r1_choff; p.R2 = r2; p.r2_stride = r2_stride; p.r2_choff = r2_choff;
   p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
   p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + TR - 1) / TR; p.tiles_x = (w + TC - 1) / TC; p.slope = slope;
+#ifdef LFSR_CONV_DIAG
+  p.dbg = g_lfsr_diag_buf;
+#endif
   long long nblk = (long long)n_img * p.tiles_y * p.tiles_x;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;
   int ncu = 256;
   {
-    static int cus[64] = {};
+    static std::atomic<int> cus[64];
     if (!cus[dev]) {
       int v = 0;
       if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus[dev] = v; else cus[dev] = 256;
@@ -337,7 +340,7 @@ int lfsr_conv3x3_halo_tail_launch(const float* x, int x_stride, int x_choff, con
                                   const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                                   const float* mk, int mk_stride, int mk_choff, float mk_slope,
                                   int n_img, int h, int w, float slope, int tile_begin, int tile_count, hipStream_t st) {
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {

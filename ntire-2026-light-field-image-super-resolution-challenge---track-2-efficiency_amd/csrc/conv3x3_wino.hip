@@ -50,6 +50,8 @@ constexpr int SMEM_BYTES = (HALO_FLOATS + XCH_FLOATS + 256) * 4;   // 153600 (+1
 
 struct WinoArgs {
   const float* X; int x_stride; int x_choff;
+  int x_bytes, y_bytes, r1_bytes, r2_bytes, mk_bytes;   // true byte span of each operand (n_img * h * w * stride * 4 < 2 GiB; 0 = absent): descriptor extents
+  float* dbg;                                           // (LFSR_CONV_DIAG builds: stamp buffer; else unused)
   const float* Wu;   // [8 stages][2 nt][16 p][2 half][32 n][4]   (lfsr_pack_wino)
   float* Y; int y_stride; int y_choff;
   const float* R1; int r1_stride; int r1_choff;
@@ -112,12 +114,11 @@ __device__ __forceinline__ void wino_tile_loop(WinoArgs p, const int bid, const 
 #ifdef LFSR_CONV_DIAG
   long long seg[32] = {};
   long long tprev = clock64();
-  float* dbgbuf = const_cast<float*>(p.R2);
-  p.R2 = nullptr;
+  float* dbgbuf = p.dbg;
 #endif
-  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, OOB), rsW = make_rsrc(p.Wu, 16 * UNIT_FLOATS * 4), rsY = make_rsrc(p.Y, OOB);
-  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, (MASK ? p.Mk : p.R1) ? OOB : 0);   // prefetched epilogue operand
-  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(MASK ? p.R1 : p.R2, (MASK ? p.R1 : p.R2) ? OOB : 0);   // late epilogue operand
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsW = make_rsrc(p.Wu, 16 * UNIT_FLOATS * 4), rsY = make_rsrc(p.Y, p.y_bytes);
+  const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, MASK ? p.mk_bytes : p.r1_bytes);   // prefetched epilogue operand
+  const __amdgpu_buffer_rsrc_t rsL = make_rsrc(MASK ? p.R1 : p.R2, MASK ? p.r1_bytes : p.r2_bytes);   // late epilogue operand
   const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
   const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
   const bool has_e = (MASK ? p.Mk : p.R1) != nullptr, has_l = (MASK ? p.R1 : p.R2) != nullptr;
@@ -483,8 +484,8 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
       if (rc != LFSR_E_ARG) return rc;
     }
   }
-  static bool attr_set[64] = {};
-  static int cus[64] = {};
+  static std::atomic<bool> attr_set[64];
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
@@ -526,6 +527,14 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
   p.ntiles = body;
   p.nbody = body < ncu ? body : ncu;
   const int wino_tail = tail_direct ? 0 : tail;
+  {
+    const long long npix4 = (long long)n_img * h * w * 4;   // (spans < 2 GiB: checked above)
+    p.x_bytes = (int)(npix4 * x_stride); p.y_bytes = (int)(npix4 * y_stride);
+    p.r1_bytes = r1 ? (int)(npix4 * r1_stride) : 0; p.r2_bytes = r2 ? (int)(npix4 * r2_stride) : 0; p.mk_bytes = mk ? (int)(npix4 * mk_stride) : 0;
+  }
+#ifdef LFSR_CONV_DIAG
+  p.dbg = g_lfsr_diag_buf;
+#endif
   const unsigned grid = (unsigned)(p.nbody + 2 * wino_tail);
   if (mk) hipLaunchKernelGGL((k_conv3x3_wino<true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
   else hipLaunchKernelGGL((k_conv3x3_wino<false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);

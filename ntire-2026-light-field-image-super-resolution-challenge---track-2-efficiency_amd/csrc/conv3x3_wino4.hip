@@ -37,10 +37,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define W4_URING 12   // depth of the U fragment ring (16-B fragments in flight per wave); must divide 144
 #endif
 
+#ifndef W4_SWAP
+#define W4_SWAP 0     // 1: waves 0..3 produce and waves 4..7 consume (which half of a workgroup is dispatched first decides VALU-issue arbitration)
+#endif
+#ifndef W4_PRIO
+#define W4_PRIO 0     // > 0: the producer waves raise their issue priority once (s_setprio), behind a provably wave-uniform branch
+#endif
+#ifndef W4_CLRELU
+#define W4_CLRELU 0   // 1: the forward activation (LeakyReLU) is applied by the consumers in At M A instead of by the producers' drain
+#endif
+#ifndef W4_SWZ
+#define W4_SWZ 0      // 1: staged halo pixels XOR-swizzled by column bit 2 so the producers' patch reads (ds_read_b32, 4 tiles per wave) are conflict-free
+#endif
+
 #ifdef LFSR_CONV_DIAG
-// diagnostic build only: wave 0 accumulates s_memtime deltas per segment, written to the buffer passed as R2
-#define STAMP(k) do { if (wave == 0) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
-#define PSTAMP(k) do { if (wave == 4) { long long t_ = clock64(); seg[k] += t_ - tprev; tprev = t_; } } while (0)
+// diagnostic build only: the first consumer wave and the first producer wave accumulate s_memtime deltas per segment into the
+// buffer set by lfsr_diag_set_buffer (64 floats per block: consumer 0..31, producer 32..63; producer segment k of step c = 32 + 8 c + k)
+#define STAMP(k) do { if (wave == (W4_SWAP ? 4 : 0)) { long long t_ = clock64(); seg[k] += (unsigned)(t_ - tprev); tprev = t_; } } while (0)
+#define PSTAMP(k) do { if (wave == (W4_SWAP ? 0 : 4)) { long long t_ = clock64(); seg[k] += (unsigned)(t_ - tprev); tprev = t_; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #define PSTAMP(k) do { } while (0)
@@ -61,7 +75,9 @@ constexpr int INV = 1 << 30;            // "outside the image" marker of a row /
 constexpr int OOB = (int)0x80000000u;
 
 struct Wino4Args {
-  const float* X; int x_stride; int x_choff; int x_bytes;
+  const float* X; int x_stride; int x_choff; int x_bytes;   // *_bytes: the operand's true byte span (n_img * h * w * stride * 4); 0 for an absent operand,
+  int y_bytes, r1_bytes, r2_bytes, mk_bytes;                //          so a mis-computed offset is a dropped access, never a stray one
+  float* dbg;                                               // (LFSR_CONV_DIAG builds: the stamp buffer set by lfsr_diag_set_buffer; else unused)
   const float* Wu;   // [16 stages][4 ns][9 q][64 lanes][4]   (lfsr_pack_wino4)
   float* Y; int y_stride; int y_choff;
   const float* R1; int r1_stride; int r1_choff;
@@ -127,24 +143,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   float* const sX = smem + 2 * VBUF;      // epilogue exchange: [4 rows a][64 pixels][64 channels]
   float* const sH = sX + 4 * 4096;        // (W4_HALO) raw halo of one chunk: [340 pixels][16 channels], then the landing zone
   const int tid = threadIdx.x & 255, lane = tid & 63, w4 = (threadIdx.x >> 6) & 3;
-  const bool producer = threadIdx.x >= 256;
+  const bool producer = W4_SWAP ? threadIdx.x < 256 : threadIdx.x >= 256;
   const int nblk = gridDim.x;
   // a block walks a CONTIGUOUS range of tiles (the next tile's patch rows share pages and two pixel rows with this one's)
   int tile = (int)(((long long)blockIdx.x * p.ntiles) / nblk);
   const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.ntiles) / nblk);
 #ifdef LFSR_CONV_DIAG
   const int wave = threadIdx.x >> 6;
-  long long seg[32] = {};
+  unsigned seg[64] = {};
   long long tprev = clock64();
-  float* dbgbuf = const_cast<float*>(p.R2);
-  p.R2 = nullptr;
+  float* dbgbuf = p.dbg;
 #endif
 
+#if W4_PRIO
+  if ((__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) != (W4_SWAP != 0)) __builtin_amdgcn_s_setprio(W4_PRIO);
+#endif
   if (producer) {
     // ======================================================= PRODUCER ==========================================================
     const int c16 = lane & 15, ptile = 4 * w4 + (lane >> 4), pty = ptile >> 3, ptx = ptile & 7;
-    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.Y, OOB);
-    const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, OOB), rsL = make_rsrc(MASK ? p.R1 : p.R2, OOB);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.Y, p.y_bytes);
+    const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, MASK ? p.mk_bytes : p.r1_bytes), rsL = make_rsrc(MASK ? p.R1 : p.R2, MASK ? p.r1_bytes : p.r2_bytes);
     const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
     const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
     auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
@@ -222,8 +240,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       for (int i = 0; i < 4; ++i) {
         const int px = (tid + 256 * i) >> 4, un = tid & 15;
         f32x4 v = *reinterpret_cast<const f32x4*>(xb + px * 64 + ((un ^ ((px >> 2) & 7)) << 2));
+        if (!(W4_CLRELU && !MASK)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+          for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+        }
         if (MASK) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] *= e[i][k] > 0.f ? 1.f : p.mk_slope;
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         hx[i] = ok ? base + __mul24(__mul24(r, p.W) + c, p.x_stride * 4) + cq * 16 : OOB;
       }
     };
-    const __amdgpu_buffer_rsrc_t rsXh = make_rsrc(p.X, OOB);
+    const __amdgpu_buffer_rsrc_t rsXh = make_rsrc(p.X, p.x_bytes);
     f32x4 hv0[6], hv1[6];
     auto halo_load = [&](f32x4 (&hv)[6], int chunk) {
 #pragma unroll
@@ -265,7 +285,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int px = (tid + 256 * i) >> 2, cq = tid & 3;
-        float* dst = (i < 5 || px < HPIX) ? sH + px * 16 + cq * 4 : sH + HBUF + (tid & 63) * 4;   // slots 340..383: landing zone
+        // W4_SWZ: pixel px lands in the slot of px ^ ((column >> 2) & 1): neighbours (px, px ^ 1) share a row and (column >> 2), so this is a permutation of pairs
+        const int pxs = W4_SWZ ? px ^ (((px - (__mul24(px, 1928) >> 16) * 34) >> 2) & 1) : px;
+        float* dst = (i < 5 || px < HPIX) ? sH + pxs * 16 + cq * 4 : sH + HBUF + (tid & 63) * 4;   // slots 340..383: landing zone
         *reinterpret_cast<f32x4*>(dst) = hv[i];
       }
     };
@@ -274,7 +296,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) raw[6 * r + c] = hR[(r * 34 + c) * 16];
+        for (int c = 0; c < 6; ++c) raw[6 * r + c] = W4_SWZ ? hR[((r * 34 + c) ^ ((ptx + (c >> 2)) & 1)) * 16] : hR[(r * 34 + c) * 16];
     };
     halo_offsets(true, img, y0, x0);
     halo_load(hv0, 0);
@@ -309,24 +331,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
           halo_store(hv);
           drain_request(c, pimg, py0, px0);
           __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(24);
+          PSTAMP(32 + 8 * c + 0);
           LDS_BARRIER();   // (A)
-          PSTAMP(25);
+          PSTAMP(32 + 8 * c + 1);
           read_raw(raw0);
           if (c == 1) halo_offsets(has_next, nimg, ny0, nx0);   // chunk c + 3 is chunk 0 of the next tile from here on
           __builtin_amdgcn_sched_barrier(0);
           if (!(W4_ABL & 1)) halo_load(hv, (c + 3) & 3);
           __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(26);
+          PSTAMP(32 + 8 * c + 2);
           if (!(W4_ABL & 2)) transform(raw0);
           if (!(W4_ABL & 4)) write_v(raw0, (c + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(27);
+          PSTAMP(32 + 8 * c + 3);
           drain_plane(c);
           __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(28);
+          PSTAMP(32 + 8 * c + 4);
           LDS_BARRIER();   // (B)
-          PSTAMP(29);
+          PSTAMP(32 + 8 * c + 5);
           continue;
         }
 #endif
@@ -335,26 +357,26 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #ifdef LFSR_CONV_DIAG
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (so that segment 24 is the wait for the patch / operand loads)
 #endif
-        PSTAMP(24);
+        PSTAMP(32 + 8 * c + 0);
         if (!(W4_ABL & 2)) transform(raw);
         __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(25);
+        PSTAMP(32 + 8 * c + 1);
         if (!(W4_ABL & 4)) write_v(raw, (c + 1) & 1);
         if (c == 1) patch_offsets(has_next, nimg, ny0, nx0);
         __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(26);
+        PSTAMP(32 + 8 * c + 2);
         if (!(W4_ABL & 1) && !((W4_ABL & 64) && c == 3) && !((W4_ABL & 128) && c == 1)) load_raw(raw, (c + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(27);
+        PSTAMP(32 + 8 * c + 3);
         // output row c of the PREVIOUS tile's Winograd tiles (pimg < 0: none): exchange plane c -> whole pixels, 16 B per lane
         drain_plane(c);
         __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(28);
+        PSTAMP(32 + 8 * c + 4);
         LDS_BARRIER();
-        PSTAMP(29);
+        PSTAMP(32 + 8 * c + 5);
       }
       LDS_BARRIER();   // this tile's results are in the exchange planes
-      PSTAMP(30);
+      PSTAMP(62);
       pimg = img; py0 = y0; px0 = x0;
       if (!has_next) {
 #pragma unroll
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     f32x4 acc[36];
     if (W4_HALO) LDS_BARRIER();   // (A of the prologue)
     LDS_BARRIER();   // (B0)
-    STAMP(31);
+    STAMP(9);
     while (true) {
       const bool has_next = tile + 1 < tile_end;
 #pragma unroll
@@ -404,7 +426,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
             const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
             if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
             __builtin_amdgcn_sched_barrier(0);       // (keeps every LDS read two groups ahead of its use)
-            if (W4_HALO && g == 3) LDS_BARRIER();    // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
+            if (W4_HALO && g == 3) { STAMP(24 + c); LDS_BARRIER(); STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
           }
         }
         STAMP(c);
@@ -419,7 +441,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         float* const xb = sX + a * 4096;
         at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(xb + xw + b * 64) = acc[6 * a + b];
+        for (int b = 0; b < 4; ++b) {
+          f32x4 v = acc[6 * a + b];
+          if (W4_CLRELU && !MASK) {   // the forward activation here: the matrix pipe idles during At M A anyway, and the producers' issue slots are the scarce resource
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = p.slope <= 1.f ? fmaxf(v[k], v[k] * p.slope) : (v[k] >= 0.f ? v[k] : v[k] * p.slope);
+          }
+          *reinterpret_cast<f32x4*>(xb + xw + b * 64) = v;
+        }
       }
       STAMP(8);
       LDS_BARRIER();   // the tile's results are in the exchange buffer (the producers drain it during the next tile's first chunk)
@@ -429,10 +458,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     }
   }
 #ifdef LFSR_CONV_DIAG
-  if (dbgbuf && threadIdx.x == 0)
-    for (int k = 0; k < 24; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
-  if (dbgbuf && threadIdx.x == 256)
-    for (int k = 24; k < 32; ++k) dbgbuf[blockIdx.x * 32 + k] = (float)seg[k];
+  if (dbgbuf && threadIdx.x == (W4_SWAP ? 256 : 0))
+    for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 64 + k] = (float)seg[k];
+  if (dbgbuf && threadIdx.x == (W4_SWAP ? 0 : 256))
+    for (int k = 32; k < 64; ++k) dbgbuf[blockIdx.x * 64 + k] = (float)seg[k];
 #endif
 }
 
@@ -476,8 +505,8 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
                               const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                               const float* mk, int mk_stride, int mk_choff, float mk_slope,
                               int n_img, int h, int w, float slope, hipStream_t st) {
-  static bool attr_set[64] = {};
-  static int cus[64] = {};
+  static std::atomic<bool> attr_set[64];
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
@@ -503,15 +532,19 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
   p.R1 = r1; p.r1_stride = r1_stride; p.r1_choff = r1_choff; p.R2 = r2; p.r2_stride = r2_stride; p.r2_choff = r2_choff;
   p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
+  const long long npix4 = (long long)n_img * h * w * 4;
+  p.y_bytes = (int)(npix4 * y_stride); p.r1_bytes = r1 ? (int)(npix4 * r1_stride) : 0; p.r2_bytes = r2 ? (int)(npix4 * r2_stride) : 0;
+  p.mk_bytes = mk ? (int)(npix4 * mk_stride) : 0;
+#ifdef LFSR_CONV_DIAG
+  p.dbg = g_lfsr_diag_buf;
+#endif
   p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + 7) / 8; p.tiles_x = (w + 31) / 32; p.slope = slope;
   const long long nt = (long long)n_img * p.tiles_y * p.tiles_x;
   if (nt <= 0 || nt > 0x7fffffffLL) return LFSR_E_ARG;
   p.ntiles = (int)nt;
   const int slots = cus[dev];
   const unsigned grid = (unsigned)(nt < slots ? nt : slots);
-#ifndef LFSR_CONV_DIAG   // (the diagnostic build passes its stamp buffer as R2)
-  if (!mk && !r1 && r2) { p.R1 = r2; p.r1_stride = r2_stride; p.r1_choff = r2_choff; p.R2 = nullptr; }   // a lone residual is the first operand
-#endif
+  if (!mk && !r1 && r2) { p.R1 = r2; p.r1_stride = r2_stride; p.r1_choff = r2_choff; p.r1_bytes = p.r2_bytes; p.R2 = nullptr; p.r2_bytes = 0; }   // a lone residual is the first operand
   if (mk && p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
   else if (mk) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
   else if (p.R1 && p.R2) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);

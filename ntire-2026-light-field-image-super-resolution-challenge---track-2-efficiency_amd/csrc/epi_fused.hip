@@ -21,7 +21,7 @@ namespace {
 constexpr int LINES = 8, LROW = 68, TROW = 36;
 
 struct EpiArgs {
-  const float* X; int x_stride; int x_choff;
+  const float* X; int x_stride; int x_choff; int x_bytes;   // x_bytes: the operand's true byte span (descriptor extent)
   const float* W1;    // [A*A][32][64]  (tap k, n, c)
   const float* W2;    // [32A][32]      (n = chunk*32 + c, k): the 1x1 weights, row-major as packed by lfsr_pack_conv_weight
   float* Y; int y_stride; int choffH; int choffV;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
   // ONCE per block (line bases from LDS, bounds -> out-of-range offsets that read as zero); a stage only adds the view's
   // wave-uniform offset.  As per-stage branches with 64-bit addresses this code sat un-overlapped in front of every stage's MFMAs.
   constexpr int EOOB = (int)0x80000000u;
-  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, EOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W1), 0, A * A * 32 * 64 * 4, 0x00020000);
   int offA[9], offW[5];
 #pragma unroll
@@ -230,7 +230,7 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   // which: 1 = horizontal only, 2 = vertical only, 3 = both
   if (!lfsr_epi_fused_ok(A, h, w)) return LFSR_E_ARG;
   if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   const int smem = (int)lfsr_epi_fused_smem(5);
@@ -244,6 +244,7 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.W1 = w1_packed; p.W2 = w2_packed;
   p.Y = y; p.y_stride = y_stride; p.choffH = choffH; p.choffV = choffV; p.TH = t_h; p.TV = t_v;
   p.B = B; p.A = A; p.H = h; p.W = w; p.slope = slope;
+  p.x_bytes = (int)((long long)B * A * A * h * w * x_stride * 4);
   p.tilesH = (which & 1) ? (B * A * h + LINES - 1) / LINES : 0;
   p.tilesV = (which & 2) ? (B * A * w + LINES - 1) / LINES : 0;
   int grid = p.tilesH + p.tilesV;

@@ -25,6 +25,7 @@ struct FfnArgs {
   const float* R; int r_stride; int r_choff;    // residual (M, N2) or null
   float* Y; int y_stride; int y_choff;
   long long M; int H;
+  int y_bytes, r_bytes;                         // true byte spans (descriptor extents; 0 = absent)
   float slope;                                  // hidden activation: 0 = ReLU
 };
 
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs p) {
   __syncthreads();
 
   float* st = sT + wave * 32 * TR;
-  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, FOOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.R ? FOOB : 0, 0x00020000);   // null residual: loads return 0
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);   // null residual: loads return 0
   float4 xa[KJ];
   f32x16 accy[NT2];
   int step = 0;
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs p) {
 template <int K1, int N2>
 int launch_ffn(const FfnArgs& p, hipStream_t st) {
   constexpr int smem = (2 * (32 * (K1 + 4) + N2 * 36) + 8 * 32 * 36) * 4;
-  static bool attr_set[64] = {};
-  static int cus[64] = {};
+  static std::atomic<bool> attr_set[64];
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
@@ -217,6 +218,7 @@ extern "C" int lfsr_ffn_fwd(const float* x, int x_stride, int x_choff, const flo
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.W1 = w1_packed; p.W2 = w2_packed;
   p.R = res; p.r_stride = res_stride; p.r_choff = res_choff; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
   p.M = M; p.H = H; p.slope = slope;
+  p.y_bytes = (int)(M * y_stride * 4); p.r_bytes = res ? (int)(M * res_stride * 4) : 0;
   hipStream_t st = lfsr_stream(stream);
   if (K1 == 128 && N2 == 128) return launch_ffn<128, 128>(p, st);
   if (K1 == 64 && N2 == 64) return launch_ffn<64, 64>(p, st);

@@ -281,7 +281,13 @@ inline unsigned grid_for(long long total) {
 
 extern "C" {
 
-const char* lfsr_version(void) { return "lfsr_hip 0.1 gfx950 (fp32 MFMA 32x32x2)"; }
+const char* lfsr_version(void) { return "lfsr_hip 0.2 gfx950 (fp32 MFMA)"; }
+#ifdef LFSR_CONV_DIAG
+}
+float* g_lfsr_diag_buf = nullptr;
+extern "C" {
+int lfsr_diag_set_buffer(float* buf) { g_lfsr_diag_buf = buf; return LFSR_OK; }
+#endif
 
 static int bad_elem(int e) { return !(e == 2 || e == 4); }
 

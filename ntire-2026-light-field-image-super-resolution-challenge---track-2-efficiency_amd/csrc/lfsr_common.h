@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/lfsr_hip.h"
 
 #define LFSR_HIP_ERR(e) (-(1000 + (int)(e)))

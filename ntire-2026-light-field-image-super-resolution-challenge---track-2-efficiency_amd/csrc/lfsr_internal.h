@@ -7,6 +7,13 @@ enum { LFSR_IN_SAME = 0, LFSR_IN_CONV3 = 1, LFSR_IN_ANG = 2, LFSR_IN_EPIH = 3, L
        LFSR_IN_CHK_H = 5, LFSR_IN_CHK_V = 6, LFSR_IN_LINE_H = 7, LFSR_IN_LINE_V = 8 };
 enum { LFSR_OUT_SAME = 0, LFSR_OUT_VIEWS = 1, LFSR_OUT_EPIH = 2, LFSR_OUT_EPIV = 3 };
 
+#ifdef LFSR_CONV_DIAG
+// diagnostic builds only (tools/build_diag.sh): buffer that receives the conv kernels' in-kernel s_memtime stamps; its own argument, never an
+// operand slot (round 1 passed it as R2, which selected the two-residual kernel variant on a null-based descriptor: DESIGN.md, incident note)
+extern float* g_lfsr_diag_buf;
+extern "C" int lfsr_diag_set_buffer(float* buf);
+#endif
+
 // conv3x3_halo.hip
 int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,

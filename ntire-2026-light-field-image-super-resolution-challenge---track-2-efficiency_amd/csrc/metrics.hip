@@ -94,6 +94,18 @@ __global__ __launch_bounds__(256) void k_mask_views(const float* __restrict__ x,
   }
 }
 
+// per-view fill values (mask_value = 'mean' with several masked views: each view gets its own mean, masked_pretraining.py:121-123)
+__global__ __launch_bounds__(256) void k_mask_views_fill(const float* __restrict__ x, float* __restrict__ y, const unsigned char* __restrict__ mask,
+                                                        const float* __restrict__ fill, long long total, int A, int h, int w) {
+  const int Wm = A * w, Hm = A * h;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    int col = (int)(i % Wm);
+    int row = (int)((i / Wm) % Hm);
+    const int v = (row / h) * A + col / w;
+    y[i] = mask[v] ? fill[v] : x[i];
+  }
+}
+
 
 // "Next" row N4 of SURVEY 8f, the output tail of test() (train.py:329-341, inference.py:205-216; utils/utils.py:191-204):
 //   rgb = uint8( clip( ycbcr2rgb(cat(Sr_SAI_y, Sr_SAI_cbcr)), 0, 1 ) * 255 ),  split into A x A views (h, w, 3)
@@ -144,6 +156,16 @@ int lfsr_mask_views(const float* x, float* y, const unsigned char* mask, float f
   unsigned grid = lfsr_blocks(total, 256);
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(k_mask_views, dim3(grid), dim3(256), 0, lfsr_stream(stream), x, y, mask, fill, total, A, h, w);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_mask_views_fill(const float* x, float* y, const unsigned char* mask, const float* fill, int B, int C, int A, int h, int w, void* stream) {
+  if (!x || !y || !mask || !fill || B <= 0 || C <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
+  long long total = (long long)B * C * A * h * A * w;
+  unsigned grid = lfsr_blocks(total, 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_mask_views_fill, dim3(grid), dim3(256), 0, lfsr_stream(stream), x, y, mask, fill, total, A, h, w);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }

@@ -156,7 +156,7 @@ template <int K, int NB, int BMR>
 int launch_rowgemm(const RowGemmArgs& p, hipStream_t st) {
   constexpr int smem = (NB + BMR) * (K + 4) * 4;
   constexpr int per_cu = smem <= 78 * 1024 ? 2 : 1;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {

@@ -331,7 +331,7 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
     if (smem_for(T1) <= 150 * 1024) {
       const int ntile1 = (n1 + T1 - 1) / T1;
       size_t smem = smem_for(T1);
-      static bool attr_set[64] = {};
+      static std::atomic<bool> attr_set[64];
       int dev = 0;
       if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_window_attn_lds<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return LFSR_E_ARG;

@@ -196,7 +196,7 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
   if (!f || !w0_packed || !w3 || !x_lr || !out || B <= 0 || A <= 0 || h <= 0 || w <= 0 || (s != 2 && s != 4)) return LFSR_E_ARG;
   if (f_stride < f_choff + 64 || (f_stride | f_choff) & 3) return LFSR_E_ARG;
   const int smem = (2 * UT_ROWS * LDS_ROW + 2 * 64 * LDS_ROW + 64 * 9) * 4;
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {

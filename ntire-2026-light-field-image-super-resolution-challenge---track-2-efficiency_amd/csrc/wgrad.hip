@@ -112,6 +112,7 @@ struct Wgrad3Args {
   const float* G; int g_stride; int g_choff;
   const float* X; int x_stride; int x_choff;
   float* P;               // [gridDim.x][9][64][64]
+  int g_bytes, x_bytes;   // true byte spans (descriptor extents)
   int n_img, H, W, tiles_y, tiles_x;
 };
 
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(512) void k_wgrad_conv3_halo(Wgrad3Args p) {
   // are out-of-range offsets that read as zero instead of per-pixel branches with 64-bit addresses
   typedef float f32x4w __attribute__((ext_vector_type(4)));
   constexpr int WOOB = (int)0x80000000u;
-  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, WOOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, WOOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
   float4 hx[7], hg[4];
   auto load_tile = [&](int tile) {
     int tx = tile % p.tiles_x; int qq = tile / p.tiles_x;
@@ -315,7 +316,7 @@ int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const flo
                             int n_img, int h, int w, hipStream_t st) {
   if (!G || !X || !P || n_img <= 0 || h <= 0 || w <= 0 || ((g_stride | g_choff | x_stride | x_choff) & 3)) return LFSR_E_ARG;
   if ((long long)n_img * h * w * (x_stride > g_stride ? x_stride : g_stride) * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets
-  static bool attr_set[64] = {};
+  static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   const int smem = (WX_PIX + WG_PIX) * LDS_ROW * 4;
@@ -326,6 +327,7 @@ int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const flo
   }
   Wgrad3Args p{};
   p.G = G; p.g_stride = g_stride; p.g_choff = g_choff; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P;
+  p.g_bytes = (int)((long long)n_img * h * w * g_stride * 4); p.x_bytes = (int)((long long)n_img * h * w * x_stride * 4);
   p.n_img = n_img; p.H = h; p.W = w; p.tiles_y = (h + WT_R - 1) / WT_R; p.tiles_x = (w + WT_C - 1) / WT_C;
   hipLaunchKernelGGL(k_wgrad_conv3_halo, dim3((unsigned)lfsr_wgrad_conv3_blocks(n_img, h, w)), dim3(512), smem, st, p);
   LFSR_CHECK_LAUNCH();

@@ -62,19 +62,27 @@ class _DistgSSRFunction(torch.autograd.Function):
         rt = model._runtime(x.device)
         ctx.model, ctx.rt = model, rt
         ctx.save_for_backward(x)
-        return rt.forward_train(x)
+        out = rt.forward_train(x)
+        ctx.generation = rt.train_generation      # the saved activations live in the runtime's ONE training workspace
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         (x,) = ctx.saved_tensors
         model, rt = ctx.model, ctx.rt
-        if model.grad_bucket is None or model.grad_bucket.device != x.device:
-            model.grad_bucket = torch.empty(rt.num_params(), dtype=torch.float32, device=x.device)
-        rt.backward(x, dout, model.grad_bucket)
+        if ctx.generation != rt.train_generation:
+            raise capi.LfsrError("DistgSSR backward: a later forward (with grad enabled) has overwritten the training workspace this "
+                                 "graph's activations lived in; run backward before the next training forward")
+        # A FRESH bucket per backward: autograd's AccumulateGrad keeps (steals) the tensors returned here as p.grad, so handing it
+        # views of a buffer that the next backward overwrites would make `p.grad += new` run on aliased memory (zero_grad(set_to_none=
+        # False) or gradient accumulation would silently double the gradients).  model.grad_bucket is the latest one.
+        bucket = torch.empty(rt.num_params(), dtype=torch.float32, device=x.device)
+        rt.backward(x, dout, bucket)
+        model.grad_bucket = bucket
         grads = []
         for name, p in model.named_parameters():
             off, n = model._spans[name]
-            grads.append(model.grad_bucket[off:off + n].view_as(p) if p.requires_grad else None)
+            grads.append(bucket[off:off + n].view_as(p) if p.requires_grad else None)
         return (None, None, *grads)
 
 
@@ -104,6 +112,11 @@ class get_model(nn.Module):
             self._rt.load_state(self.state_dict().items(), device)
             self._rt_version = ver
         return self._rt
+
+    def invalidate_packed(self):
+        """Force a repack of the HIP library's weight copies at the next forward.  The runtime notices parameter updates through
+        (data_ptr, _version); writes that bypass the version counter (``p.data.copy_``, collectives on ``p.data``) must call this."""
+        self._rt_version = None
 
     def forward(self, x, info=None):
         if not x.is_cuda:

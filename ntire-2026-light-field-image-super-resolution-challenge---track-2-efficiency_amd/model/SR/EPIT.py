@@ -67,6 +67,10 @@ class get_model(nn.Module):
             self._rt_version = ver
         return self._rt
 
+    def invalidate_packed(self):
+        """Force a repack at the next forward (for weight writes that bypass p._version: ``p.data.copy_``, collectives)."""
+        self._rt_version = None
+
     def forward(self, lr, info=None):
         if not lr.is_cuda:
             raise capi.LfsrError("EPIT: input must live on the MI355X (no CPU fallback in the HIP path)")

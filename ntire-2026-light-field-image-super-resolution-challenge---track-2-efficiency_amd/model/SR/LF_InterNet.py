@@ -79,6 +79,10 @@ class get_model(nn.Module):
             self._rt_version = ver
         return self._rt
 
+    def invalidate_packed(self):
+        """Force a repack at the next forward (for weight writes that bypass p._version: ``p.data.copy_``, collectives)."""
+        self._rt_version = None
+
     def forward(self, x, Lr_info=None):
         if not x.is_cuda:
             raise capi.LfsrError("LF_InterNet: input must live on the MI355X (no CPU fallback in the HIP path)")

@@ -41,5 +41,9 @@ def train_step(net, criterion, optimizer, x, label, group=None, max_norm=1.0, da
 def broadcast_parameters(net, group=None, src=0):
     """Identical replicas at start: rank ``src``'s weights to everyone."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        for p in net.parameters():
-            dist.broadcast(p.data, src=src, group=group)
+        with torch.no_grad():
+            for p in net.parameters():
+                dist.broadcast(p, src=src, group=group)
+    # a collective writes through the storage without bumping p._version, which is what the HIP runtimes key their packed copies on
+    if hasattr(net, "invalidate_packed"):
+        net.invalidate_packed()

@@ -1,8 +1,11 @@
 """Masked angular pre-training on the device: the reference's ``MaskedAngularPretraining`` /
 ``ProgressiveMasking`` (utils/masked_pretraining.py:34-226), same constructor arguments, strategies, 50 % skip, never-mask-the-
 centre rule and ``(x_masked, mask_info)`` return; the view fill runs as one kernel through the C ABI instead of a Python loop of
-slice assignments.  View selection stays on the host with Python's ``random`` exactly as upstream (so a seeded run picks the same
-views).  ``mask_value='noise'`` (host-generated randn per view upstream) is not built."""
+slice assignments.  View selection stays on the host with Python's ``random`` exactly as upstream (``plan()`` consumes the generator
+in upstream's order, so a seeded run picks the same views -- pinned on the reference in tests/golden/aux.json).
+``mask_value``: 'zero' and 'mean' (each masked view filled with its own mean, upstream :121-123) run through the C ABI;
+'noise' (upstream :124-127: ``torch.randn_like(view) * 0.1`` per view from torch's global generator) stays the same torch call per
+view, so a seeded run draws what upstream draws on the same device."""
 import random
 
 import torch
@@ -37,31 +40,44 @@ class MaskedAngularPretraining(nn.Module):
             return [v for _, v in d[:self.num_masked]]
         return random.sample(views, min(self.num_masked, len(views)))
 
-    def forward(self, x):
+    def plan(self):
+        """Host-side decision of one call, consuming ``random`` exactly as upstream's forward does (:95-105): None = pass through."""
         if not self.training and not self.enable_in_eval:
-            return x, {'masked': False, 'mask_ratio': 0.0}
+            return None
         if random.random() > 0.5:
+            return None
+        return self._get_mask_indices()
+
+    def forward(self, x):
+        idx = self.plan()
+        if idx is None:
             return x, {'masked': False, 'mask_ratio': 0.0}
-        if self.mask_value not in ('zero', 'mean'):
-            raise NotImplementedError("mask_value 'noise' is not built on the device path")
         B, C, H, W = x.shape
         A = self.angRes
-        idx = self._get_mask_indices()
-        if self.mask_value == 'mean' and len(idx) > 1:
-            raise NotImplementedError("mask_value 'mean' fills each view with its own mean upstream; device path supports one view")
+        h, w = H // A, W // A
+        info = {'masked': True, 'mask_ratio': len(idx) / self.total_views, 'mask_indices': idx, 'strategy': self.mask_strategy}
+        if self.mask_value == 'noise':
+            out = x.clone()
+            for (i, j) in idx:
+                out[:, :, i * h:(i + 1) * h, j * w:(j + 1) * w] = torch.randn_like(x[:, :, i * h:(i + 1) * h, j * w:(j + 1) * w]) * 0.1
+            return out, info
+        if self.mask_value not in ('zero', 'mean'):
+            return x.clone(), info                      # upstream: an unknown mask_value leaves the clone untouched
         flags = torch.zeros(A * A, dtype=torch.uint8)
         for (i, j) in idx:
             flags[i * A + j] = 1
         flags = flags.to(x.device)
-        fill = 0.0
-        if self.mask_value == 'mean':
-            (i, j), h, w = idx[0], H // A, W // A
-            fill = float(x[:, :, i * h:(i + 1) * h, j * w:(j + 1) * w].mean())
         xin = x.detach().float().contiguous()
         out = torch.empty_like(xin)
-        capi.check(capi.load().lfsr_mask_views(capi.dev_ptr(xin), capi.dev_ptr(out), capi.dev_ptr(flags), fill, B, C, A, H // A, W // A,
-                                               capi.stream_ptr()), "mask_views")
-        return out, {'masked': True, 'mask_ratio': len(idx) / self.total_views, 'mask_indices': idx, 'strategy': self.mask_strategy}
+        lib = capi.load()
+        if self.mask_value == 'mean':
+            fill = xin.view(B, C, A, h, A, w).mean(dim=(0, 1, 3, 5)).reshape(A * A).contiguous()    # every view's own mean
+            capi.check(lib.lfsr_mask_views_fill(capi.dev_ptr(xin), capi.dev_ptr(out), capi.dev_ptr(flags), capi.dev_ptr(fill), B, C, A, h, w,
+                                                capi.stream_ptr()), "mask_views_fill")
+        else:
+            capi.check(lib.lfsr_mask_views(capi.dev_ptr(xin), capi.dev_ptr(out), capi.dev_ptr(flags), 0.0, B, C, A, h, w,
+                                           capi.stream_ptr()), "mask_views")
+        return out, info
 
 
 class ProgressiveMasking(nn.Module):

@@ -203,11 +203,82 @@ def gen_distg_grads(out):
     print("grads: loss", loss.item(), "n", len(names))
 
 
+def gen_aux(out):
+    """Pins for the "next" rows N3 / N4 taken from the reference itself:
+    * utils/masked_pretraining.py (torch only -> imported by file path): for every strategy and mask_value in {zero, mean} the
+      sequence of (masked?, mask_indices) of 8 training-mode calls under ``random.seed(4)`` and the masked tensors;
+    * utils/utils.py:181-204 ``rgb2ycbcr`` / ``ycbcr2rgb`` (AST-extracted: the module itself needs skimage/xlwt) driven exactly as
+      train.py:332-334 drives them: uint8 view stacks.
+    N2 (SSIM): skimage is not installed in this image, so the reference's cal_metrics cannot be run; the oracle's SSIM restatement stays
+    pinned on scipy.ndimage.gaussian_filter only (tests/test_metrics_masking.py) -- recorded in aux.json."""
+    import importlib.util
+    import random
+    from einops import rearrange
+    spec = importlib.util.spec_from_file_location("ref_masked_pretraining", os.path.join(REF, "utils/masked_pretraining.py"))
+    MP = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(MP)
+    A, h, w = 5, 6, 8
+    x = torch.from_numpy(synth_input((3, 1, A * h, A * w), seed=5))
+    meta = {"masking": {"A": A, "h": h, "w": w, "B": 3, "input_seed": 5, "python_random_seed": 4, "mask_ratio": 0.3, "calls": 8, "cases": {}},
+            "ssim_pin": "scipy.ndimage.gaussian_filter only (skimage absent from the image: utils/utils.py:91-134 cannot be imported)"}
+    arrs = {}
+    for strategy in ("random", "grid", "corners", "center"):
+        for value in ("zero", "mean"):
+            m = MP.MaskedAngularPretraining(angRes=A, mask_ratio=0.3, mask_strategy=strategy, mask_value=value).train()
+            random.seed(4)
+            calls = []
+            for c in range(8):
+                y, info = m(x)
+                if info["masked"]:
+                    calls.append([[int(i), int(j)] for (i, j) in info["mask_indices"]])
+                    if value == "mean":
+                        arrs[f"mask_{strategy}_{value}_{c}"] = y.numpy()
+                    else:   # 'zero' output follows from the indices: keep its checksum only
+                        meta["masking"].setdefault("zero_sha256", {})[f"{strategy}_{c}"] = sha(y.numpy())
+                else:
+                    assert y is x
+                    calls.append(None)
+            meta["masking"]["cases"][f"{strategy}_{value}"] = calls
+    pm = MP.ProgressiveMasking(angRes=A, start_ratio=0.1, end_ratio=0.4, warmup_epochs=20)
+    prog = []
+    for ep in (0, 5, 10, 20, 30):
+        pm.set_epoch(ep)
+        prog.append([ep, pm.masker.mask_ratio, pm.masker.num_masked])
+    meta["masking"]["progressive"] = prog
+    # ---- YCbCr <-> RGB (utils/utils.py:181-204), driven as train.py:332-334 does
+    src = open(os.path.join(REF, "utils/utils.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("rgb2ycbcr", "ycbcr2rgb")]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "ref_color", "exec"), ns)
+    rng = np.random.default_rng(8)
+    ycc_cases = {}
+    for (A2, h2, w2) in [(5, 32, 32), (3, 7, 10)]:
+        y = (rng.random((A2 * h2, A2 * w2)) * 1.2 - 0.1).astype(np.float32)
+        cc = (rng.random((2, A2 * h2, A2 * w2)) * 1.2 - 0.1).astype(np.float32)
+        Sr_SAI_ycbcr = torch.cat((torch.from_numpy(y)[None, None], torch.from_numpy(cc)[None]), dim=1)
+        Sr_SAI_rgb = (ns["ycbcr2rgb"](Sr_SAI_ycbcr.squeeze().permute(1, 2, 0).numpy()).clip(0, 1) * 255).astype("uint8")
+        Sr_4D_rgb = rearrange(Sr_SAI_rgb, "(a1 h) (a2 w) c -> a1 a2 h w c", a1=A2, a2=A2)
+        key = f"A{A2}_{h2}x{w2}"
+        arrs["ycc_y_" + key], arrs["ycc_cbcr_" + key], arrs["rgb_u8_" + key] = y, cc, Sr_4D_rgb
+        ycc_cases[key] = dict(A=A2, h=h2, w=w2)
+    rgb = rng.random((9, 13, 3))
+    arrs["rgb_in"], arrs["ycbcr_of_rgb"] = rgb, ns["rgb2ycbcr"](rgb)
+    meta["ycbcr"] = {"cases": ycc_cases, "numpy": np.__version__}
+    np.savez_compressed(os.path.join(out, "aux.npz"), **arrs)
+    json.dump(meta, open(os.path.join(out, "aux.json"), "w"), indent=1)
+    print("aux:", len(arrs), "arrays")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "aux":
+        gen_aux(HERE)
+        sys.exit(0)
     torch.manual_seed(0)
     torch.set_num_threads(8)
     gen_index_ops(HERE)
     gen_models(HERE)
     gen_distg_grads(HERE)
+    gen_aux(HERE)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE))
     print("fixture bytes:", tot)

@@ -363,3 +363,19 @@ def test_distgssr_other_angres_and_scales(A, s, h, w, B):
     ref = O.distgssr_forward(x, sd, A, s)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < ATOL
+
+
+def test_batch32_equals_single_patches():
+    """configs[1] at its own batch: the B = 32 forward equals the same 32 patches run one at a time, bit for bit (tile scheduling of
+    the persistent kernels changes with B; the arithmetic per patch must not), and patch 0 / 31 match the oracle."""
+    case, sd, _, _ = model_case("DistgSSR", "full")
+    rt = capi.DistgSSRRuntime(5, 4)
+    rt.load_state([(k, torch.from_numpy(v).cuda()) for k, v in sd.items()], torch.device("cuda", 0))
+    x = torch.from_numpy(synth_input((32, 1, 160, 160), seed=1)).cuda()
+    y = rt.forward(x).clone()
+    assert torch.isfinite(y).all()
+    for i in range(32):
+        assert torch.equal(rt.forward(x[i:i + 1]), y[i:i + 1]), i
+    for i in (0, 31):
+        ref = O.distgssr_forward(x[i:i + 1].cpu().numpy(), sd, 5, 4, dtype=np.float32)
+        assert np.abs(y[i:i + 1].cpu().numpy() - ref).max() < 1e-4

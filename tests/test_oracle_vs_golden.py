@@ -119,6 +119,18 @@ def test_torch_port_distgssr(tag):
     assert np.abs(y - npz[tag + "_out"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("name,tag", [("EPIT", "a5h8s4"), ("EPIT", "a3h6w8s2"), ("LFT", "a5h8s4"), ("LFT", "a3h6w8s2"),
+                                      ("LF_InterNet", "a5h8s2"), ("LF_InterNet", "a3h6w8s4")])
+def test_torch_port_other_models(name, tag):
+    """the torch-CPU forms timed as bench.py's cpu_baseline lines for configs 1, 3, 5 against the reference's outputs"""
+    torch = pytest.importorskip("torch")
+    from oracle import lfsr_torch_port as T
+    fn = {"EPIT": T.epit_forward, "LFT": T.lft_forward, "LF_InterNet": T.internet_forward}[name]
+    case, sd, x, npz = model_case(name, tag)
+    y = fn(torch.from_numpy(x), {k: torch.from_numpy(v) for k, v in sd.items()}, case["A"], case["s"]).numpy()
+    assert np.abs(y - npz[tag + "_out"]).max() < 1e-5
+
+
 @pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
 def test_epit_small(tag):
     case, sd, x, npz = model_case("EPIT", tag)

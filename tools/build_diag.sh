@@ -9,5 +9,6 @@ for f in $(grep '^SRCS' $P/Makefile | sed 's/SRCS *:= *//'); do
   while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 0.2; done
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls _diag/obj/*.o | grep -v wino_abl) -o _diag/liblfsr_diag.so
+OBJS=""; for f in $(grep '^SRCS' $P/Makefile | sed 's/SRCS *:= *//'); do OBJS="$OBJS _diag/obj/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o _diag/liblfsr_diag.so
 ls -la _diag/liblfsr_diag.so

@@ -11,20 +11,28 @@ n_img, h, w = int(os.environ.get('N_IMG', '800')), 32, 32
 M = n_img * h * w
 x = torch.randn(M, 64, device="cuda"); wt = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
 wp = capi.pack_conv_weight(wt); y = torch.empty(M, 64, device="cuda"); r = torch.randn(M, 64, device="cuda")
-dbg = torch.zeros(256 * 32 // 4, 4, device="cuda")   # 2-D so the wrapper takes a stride; stride is unused by the DIAG build
-for res in ((None,) if os.environ.get('LFSR_CONV3X3', '') == '' else (None, r)):
+dbg = torch.zeros(256 * 64, device="cuda")
+import ctypes
+lib.lfsr_diag_set_buffer.restype = ctypes.c_int; lib.lfsr_diag_set_buffer.argtypes = [ctypes.c_void_p]
+assert lib.lfsr_diag_set_buffer(ctypes.c_void_p(dbg.data_ptr())) == 0   # the DIAG build's own stamp-buffer argument (never an operand slot)
+for res in (None, r):
+    dbg.zero_()
     for _ in range(5):
-        capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=res, res2=dbg, out=y)   # R2 carries the debug buffer in the DIAG build
+        capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=res, out=y)
     torch.cuda.synchronize()
     sel = os.environ.get("LFSR_CONV3X3", "")
     if sel == "":   # F(4x4,3x3) kernel (default): per (chunk, stage) segments, chunk barriers, the epilogue at the head of a pass
-        d = dbg.reshape(256, 32).cpu().double()
-        names = (["chunk %d MFMA stream" % k for k in range(4)] + ["-"] * 4 + ["At M A + exchange writes"] + ["-"] * 7
+        d = dbg.reshape(256, 64).cpu().double()
+        names = (["chunk %d MFMA stream after A" % k for k in range(4)] + ["-"] * 4 + ["At M A + exchange writes"] + ["-"] * 7
                  + ["barrier after chunk %d" % c for c in range(4)] + ["exchange barrier"] + ["-"] * 3
-                 + ["P: halo registers -> LDS (+ operand request)", "P: barrier A wait", "P: patch reads + next halo request", "P: input transform + V writes", "P: drain a plane", "P: chunk barrier wait", "P: exchange barrier wait", "-"])
-        tot = d[:, :24].sum(1).mean()
-        print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block)")
-        for k in range(32):
+                 + ["chunk %d MFMA stream before A" % c for c in range(4)] + ["chunk %d barrier A wait" % c for c in range(4)])
+        for c in range(4):
+            names += [f"P step {c}: halo registers -> LDS (+ operand request)", f"P step {c}: barrier A wait", f"P step {c}: patch reads + next halo request",
+                      f"P step {c}: input transform + V writes", f"P step {c}: drain a plane", f"P step {c}: chunk barrier wait", "-", "-"]
+        names[62] = "P: exchange barrier wait"
+        tot = d[:, :32].sum(1).mean()
+        print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block); producer total {d[:, 32:].sum(1).mean():.0f}")
+        for k in range(64):
             if names[k] == '-': continue
             print(f"   {names[k]:28s} {d[:, k].mean():12.0f} cyc  {100 * d[:, k].mean() / tot:5.1f}%   per tile {d[:, k].mean() / (n_img * 4 / 256):9.0f}")
         continue
