@@ -121,10 +121,25 @@ def cpu_baseline(sd_np, x_np):
     sdt = {k: torch.from_numpy(v) for k, v in sd_np.items()}
     x4 = torch.from_numpy(np.ascontiguousarray(x_np[:4]))
     sweep = []
-    cands = sorted({max(1, phys // 2), phys, min(logical, 2 * phys)})
+    # short sweep at and below the physical-core count (a GPU box hands a job a CPU share well under what the affinity mask shows, and
+    # oversubscribed oneDNN threads collapse: 256 threads ran 40x slower than 64 on the round-2 box); a candidate whose warm-up already
+    # takes > 8 s is not timed further
+    cands = sorted({c for c in (8, 16, 32, 64, min(phys, 64)) if c <= phys})
     for nt in cands:
         torch.set_num_threads(nt)
-        n, el = _time_cpu(lambda: T.distgssr_forward(x4, sdt, A, S), 4.0, 3)
+        t0 = time.perf_counter()
+        T.distgssr_forward(x4, sdt, A, S)
+        warm = time.perf_counter() - t0
+        if warm > 8.0:
+            sweep.append({"threads": nt, "patches_per_s": 4 / warm, "iters": 0, "note": "warm-up only (slow)"})
+            continue
+        n, t0 = 0, time.perf_counter()
+        while True:
+            T.distgssr_forward(x4, sdt, A, S)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > 3.0 or n >= 3:
+                break
         sweep.append({"threads": nt, "patches_per_s": 4 * n / el, "iters": n})
     best = max(sweep, key=lambda r: r["patches_per_s"])
     torch.set_num_threads(best["threads"])
@@ -376,8 +391,8 @@ def bench_infer(args, rank, world, dev, dist):
         npx = float(M)
         cls_spec = {   # class -> (kernel, bound, bytes, flop)
             "epiconv": ("k_epi (both EPI passes: 1xA^2 conv 64->32, LReLU, 1x1 32->160, LReLU, PixelShuffle1D; DistgSSR.py:91-97,108)", "mfma",
-                        (64 + 64) * npx * 4, 2 * (16.78e9 + 1.68e9) * B),
-            "pointwise": ("fuse.0 144->64 + LReLU (DistgSSR.py:98-100,109)", "hbm", (144 + 64) * npx * 4, 0.472e9 * 16 / 16 * B),
+                        (64 + 64) * npx * 4, 2 * (0.524e9 + 0.052e9) * B),
+            "pointwise": ("fuse.0 144->64 + LReLU (DistgSSR.py:98-100,109)", "hbm", (144 + 64) * npx * 4, 0.472e9 * B),
             "angconv": ("k_ang_fused (AngConv.0 + LReLU + AngConv.2 + LReLU + PixelShuffle(A); DistgSSR.py:84-90)", "hbm", (64 + 16) * npx * 4, 0.065e9 * B),
             "init_conv": ("k_initconv (SAI2MacPI + 3x3 1->64; DistgSSR.py:22,31-32)", "hbm", (1 + 64) * npx * 4, 0.029e9 * B),
             "upsample_head": ("k_head<4> (MacPI2SAI + folded 64->16 1x1 + PixelShuffle(4) + bilinear skip; DistgSSR.py:24-35)", "hbm",

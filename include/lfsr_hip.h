@@ -13,7 +13,8 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return value: 0 on success, LFSR_E_ARG (-1) for a bad argument, LFSR_E_WS (-2) for a too-small
  *     workspace, -(1000 + hipError_t) for a HIP runtime failure.  No exceptions cross the ABI;
- *   - re-entrant; no global state.
+ *   - re-entrant; the only process-wide state is per-device caches of idempotent function attributes / CU counts (atomic flags) and the
+ *     lazily resolved RCCL entry points.
  *
  * Tensor layouts
  *   NCHW "SAI mosaic"  (B,C,A*h,A*w)  element [b,c,u*h+y,v*w+x]      -- what the reference passes around
@@ -169,6 +170,43 @@ int lfsr_distgssr_forward_train(lfsr_distgssr* ctx, const float* x, float* out, 
 /* dout (B,1,A*h*s,A*w*s) = dLoss/dOut; grads: n_grads == lfsr_distgssr_num_params(ctx) floats, overwritten */
 int lfsr_distgssr_backward(lfsr_distgssr* ctx, const float* x, const float* dout, int B, int h, int w,
                            void* workspace, size_t workspace_bytes, float* grads, size_t n_grads, void* stream);
+
+/* ---- operator-level backward entry points (SURVEY 8b export list: conv3x3 dgrad / wgrad, pointwise bwd, upsample_head bwd).
+ * They replace what autograd derives from nn.Conv2d in the reference's training step (train.py:256-264, fp32). ---- */
+/* transposed pack used by the data gradients: w (O,C,kh,kw) raw PyTorch layout -> [tap'][Cpad][O] (3x3: taps flipped; O = C = 64, taps = 9
+ * is followed by the Winograd-domain copies, as lfsr_pack_conv_weight does) */
+size_t lfsr_packed_weight_tr_floats(int O, int C, int taps);
+int lfsr_pack_conv_weight_tr(const float* w, float* packed_T, int O, int C, int taps, void* stream);
+/* dx = (conv3x3^T(dy)) * LeakyReLU'(act) + r1: `act` = the saved output of the LeakyReLU(act_slope) in front of this conv's input
+ * (NULL: none), r1 = a gradient arriving over a skip connection (NULL: none).  64 -> 64, per-view zero pad 1. */
+int lfsr_conv3x3_dgrad(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, float* dx, int dx_stride, int dx_choff,
+                       const float* r1, int r1_stride, int r1_choff, const float* act, int act_stride, int act_choff, float act_slope,
+                       int n_img, int h, int w, void* stream);
+/* dw (64,64,3,3) raw PyTorch layout [= or += if accumulate] sum_pixels dy (x) shifted x; workspace: per-block partial slabs, reduced in a
+ * second deterministic pass (no float atomics) */
+size_t lfsr_conv3x3_wgrad_workspace_floats(int n_img, int h, int w);
+int lfsr_conv3x3_wgrad(const float* dy, int dy_stride, int dy_choff, const float* x, int x_stride, int x_choff, float* dw,
+                       float* workspace, size_t workspace_floats, int n_img, int h, int w, int accumulate, void* stream);
+/* 1x1 conv y = x W^T, W (cout = 64, cin): dx = (dy W) * LeakyReLU'(act);  dw (cout, cin) = dy^T x  (cout <= 64) */
+int lfsr_pointwise_dgrad(const float* dy, int dy_stride, int dy_choff, int cout, const float* wT_packed, float* dx, int dx_stride, int dx_choff, int cin,
+                         const float* act, int act_stride, int act_choff, float act_slope, long long M, void* stream);
+size_t lfsr_pointwise_wgrad_workspace_floats(long long M, int cout, int cin);
+int lfsr_pointwise_wgrad(const float* dy, int dy_stride, int dy_choff, int cout, const float* x, int x_stride, int x_choff, int cin, float* dw,
+                         float* workspace, size_t workspace_floats, long long M, int accumulate, void* stream);
+/* data gradient of lfsr_upsample_head_fwd w.r.t. f: dout (B,1,A*h*s,A*w*s) -> df (pixels, 64) VCL; g16 (pixels, 16) scratch that receives the
+ * un-shuffled output gradient (the operand of the folded matrix' weight gradient) */
+int lfsr_upsample_head_dgrad(const float* dout, const float* wf, float* df, float* g16, int B, int A, int h, int w, int s, void* stream);
+
+/* ---- the exchange step of data-parallel training: in-place sum-all-reduce of n fp32 values over RCCL (xGMI) -----------
+ * The reference has no gradient exchange (single process; option.py:28 `--local_rank` is vestigial).  `comm` is an ncclComm_t created by
+ * lfsr_comm_init (or by the caller with RCCL directly); unique_id = the 128-byte ncclUniqueId obtained on rank 0 and shipped to the others by
+ * the host.  RCCL is resolved at run time (dlopen): lfsr_comm_available() is 0 on a host without it, and the calls then return LFSR_E_ARG.
+ * Return: 0, LFSR_E_ARG, or -(2000 + ncclResult_t). */
+int lfsr_comm_available(void);
+int lfsr_comm_unique_id(void* id128);
+int lfsr_comm_init(void** comm, int world, int rank, const void* id128);
+int lfsr_comm_destroy(void* comm);
+int lfsr_allreduce(void* grads, size_t n, void* comm, void* stream);
 
 /* Per-operator-class timing with hipEvents recorded on the launch stream around every launch of the
  * forward (measurement aid for bench.py's roofline line; off by default).

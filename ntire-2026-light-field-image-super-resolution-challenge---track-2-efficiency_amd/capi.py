@@ -91,6 +91,20 @@ SIGNATURES = {
     "lfsr_epit_finalize": (c_i, [c_p, c_p]),
     "lfsr_epit_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "lfsr_epit_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "lfsr_packed_weight_tr_floats": (c_sz, [c_i, c_i, c_i]),
+    "lfsr_pack_conv_weight_tr": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "lfsr_conv3x3_dgrad": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_f, c_i, c_i, c_i, c_p]),
+    "lfsr_conv3x3_wgrad_workspace_floats": (c_sz, [c_i, c_i, c_i]),
+    "lfsr_conv3x3_wgrad": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_pointwise_dgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_f, C.c_longlong, c_p]),
+    "lfsr_pointwise_wgrad_workspace_floats": (c_sz, [C.c_longlong, c_i, c_i]),
+    "lfsr_pointwise_wgrad": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_sz, C.c_longlong, c_i, c_p]),
+    "lfsr_upsample_head_dgrad": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_comm_available": (c_i, []),
+    "lfsr_comm_unique_id": (c_i, [c_p]),
+    "lfsr_comm_init": (c_i, [C.POINTER(c_p), c_i, c_i, c_p]),
+    "lfsr_comm_destroy": (c_i, [c_p]),
+    "lfsr_allreduce": (c_i, [c_p, c_sz, c_p, c_p]),
     "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
     "lfsr_distgssr_profile_read": (c_i, [c_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
@@ -516,3 +530,89 @@ class ModelRuntime:
         ws = self.ws[key]
         check(self._f("forward")(self.ctx, dev_ptr(x), dev_ptr(out), B, h, w, dev_ptr(ws), ws.numel(), stream_ptr()), f"{self.name}_forward")
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# operator-level backward wrappers (d11) and the RCCL exchange step at the C ABI
+# ---------------------------------------------------------------------------------------------------
+
+def pack_conv_weight_T(w):
+    """(O,C,kh,kw) -> the transposed pack the data gradients read (3x3: taps flipped)."""
+    lib = load()
+    O, Cc = w.shape[:2]
+    taps = w.numel() // (O * Cc)
+    out = torch.empty(lib.lfsr_packed_weight_tr_floats(O, Cc, taps), dtype=torch.float32, device=w.device)
+    check(lib.lfsr_pack_conv_weight_tr(dev_ptr(w), dev_ptr(out), O, Cc, taps, stream_ptr()), "pack_conv_weight_T")
+    return out
+
+
+def conv3x3_dgrad(dy, wT_packed, n_img, h, w, res1=None, act=None, act_slope=1.0):
+    lib = load()
+    dx = torch.empty((n_img * h * w, 64), dtype=torch.float32, device=dy.device)
+    check(lib.lfsr_conv3x3_dgrad(dev_ptr(dy), dy.shape[1], 0, dev_ptr(wT_packed), dev_ptr(dx), 64, 0,
+                                 _opt(res1), res1.shape[1] if res1 is not None else 0, 0,
+                                 _opt(act), act.shape[1] if act is not None else 0, 0, act_slope, n_img, h, w, stream_ptr()), "conv3x3_dgrad")
+    return dx
+
+
+def conv3x3_wgrad(dy, x, n_img, h, w, dw=None):
+    lib = load()
+    acc = dw is not None
+    if dw is None:
+        dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=dy.device)
+    ws = torch.empty(lib.lfsr_conv3x3_wgrad_workspace_floats(n_img, h, w), dtype=torch.float32, device=dy.device)
+    check(lib.lfsr_conv3x3_wgrad(dev_ptr(dy), dy.shape[1], 0, dev_ptr(x), x.shape[1], 0, dev_ptr(dw), dev_ptr(ws), ws.numel(), n_img, h, w, int(acc),
+                                 stream_ptr()), "conv3x3_wgrad")
+    return dw
+
+
+def pointwise_dgrad(dy, wT_packed, cin, act=None, act_slope=1.0):
+    lib = load()
+    M = dy.shape[0]
+    dx = torch.empty((M, cin), dtype=torch.float32, device=dy.device)
+    check(lib.lfsr_pointwise_dgrad(dev_ptr(dy), dy.shape[1], 0, 64, dev_ptr(wT_packed), dev_ptr(dx), cin, 0, cin,
+                                   _opt(act), act.shape[1] if act is not None else 0, 0, act_slope, M, stream_ptr()), "pointwise_dgrad")
+    return dx
+
+
+def pointwise_wgrad(dy, x, cout, cin):
+    lib = load()
+    M = dy.shape[0]
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
+    ws = torch.empty(lib.lfsr_pointwise_wgrad_workspace_floats(M, cout, cin), dtype=torch.float32, device=dy.device)
+    check(lib.lfsr_pointwise_wgrad(dev_ptr(dy), dy.shape[1], 0, cout, dev_ptr(x), x.shape[1], 0, cin, dev_ptr(dw), dev_ptr(ws), ws.numel(), M, 0,
+                                   stream_ptr()), "pointwise_wgrad")
+    return dw
+
+
+class RcclComm:
+    """ncclComm_t created through the C ABI (lfsr_comm_*).  The 128-byte unique id comes from rank 0 and is shipped by the caller
+    (``exchange``: a callable rank-0-bytes -> bytes-on-every-rank, e.g. a torch.distributed broadcast over gloo, or a Store)."""
+
+    def __init__(self, world, rank, exchange=None):
+        self.lib = load()
+        if not self.lib.lfsr_comm_available():
+            raise LfsrError("RCCL not found (librccl.so): lfsr_allreduce is unavailable on this host")
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            check(self.lib.lfsr_comm_unique_id(buf), "comm_unique_id")
+        raw = bytes(buf.raw)
+        if world > 1:
+            if exchange is None:
+                raise LfsrError("world > 1 needs an `exchange` callable to ship rank 0's unique id")
+            raw = exchange(raw)
+        comm = c_p()
+        check(self.lib.lfsr_comm_init(C.byref(comm), world, rank, C.create_string_buffer(raw, 128)), "comm_init")
+        self.comm, self.world = comm, world
+
+    def allreduce_(self, t):
+        """in-place SUM over the communicator on the current stream; t: contiguous fp32 CUDA tensor"""
+        if t.dtype != torch.float32:
+            raise LfsrError("lfsr_allreduce carries fp32 buckets")
+        check(self.lib.lfsr_allreduce(dev_ptr(t), t.numel(), self.comm, stream_ptr()), "allreduce")
+        return t
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.lfsr_comm_destroy(self.comm)
+            self.comm = None

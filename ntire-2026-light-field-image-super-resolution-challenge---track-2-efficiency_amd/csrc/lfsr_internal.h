@@ -80,6 +80,11 @@ int lfsr_pack_weight_chunkT(const float* w, float* out, int O, int C, int ch, in
 int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
                         const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st);
 
+// attn_mfma.hip: EPI attention on MFMA; LFSR_E_ARG = geometry not covered
+int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,
+                              float* o, int o_stride, int o_choff, int nheads, int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
+                              int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, hipStream_t st);
+
 // wgrad.hip
 int lfsr_wgrad_splits(int M, int ntaps, int K);
 size_t lfsr_wgrad_partial_floats(int M, int ntaps, int N, int K);

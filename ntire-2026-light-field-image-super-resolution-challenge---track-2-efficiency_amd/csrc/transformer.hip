@@ -322,6 +322,16 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
   p.n1 = n1; p.n2 = n2; p.st1 = st1; p.st2 = st2; p.l1 = l1; p.r1 = r1; p.l2 = l2; p.r2 = r2; p.clip2 = clip2 > 0 ? clip2 : n2;
   p.scale = 1.0f / sqrtf((float)hd);
   p.total = (long long)ns0 * ns1 * ns2 * n1 * n2 * nheads;
+  // EPI geometry (every angular position visible, <= 160 tokens per sequence, heads of 16): QK^T / softmax / PV on the matrix pipe
+  // (attn_mfma.hip); LFSR_ATTN=valu keeps the VALU kernels below (A/B runs)
+  {
+    const char* asel = getenv("LFSR_ATTN");
+    if (hd == 16 && !(asel && asel[0] == 'v') && !getenv("LFSR_ATTN_L1")) {
+      const int rc = lfsr_epi_attn_mfma_launch(q, q_stride, q_choff, k, k_stride, k_choff, v, v_stride, v_choff, o, o_stride, o_choff, nheads, ns0, ns1, ns2,
+                                               bs0, bs1, bs2, n1, n2, st1, st2, l1, r1, l2, r2, clip2, lfsr_stream(stream));
+      if (rc != LFSR_E_ARG) return rc;
+    }
+  }
   // LDS-tiled path (hd 16, heads in pairs): stage the keys a tile of queries can see once; used when the staged tile fits
   if (hd == 16 && nheads % 2 == 0 && !getenv("LFSR_ATTN_L1")) {
     constexpr int HB = 2, TS = HB * 32 + 4;

@@ -70,10 +70,17 @@ def test_ffn_fused(K1, H, M):
 
 
 @pytest.mark.parametrize("vertical", [0, 1])
-def test_epi_attention_vs_masked_mha(vertical):
-    """window predicate == the reference's additive -inf mask (EPIT.py:93-108) inside nn.MultiheadAttention's core"""
+@pytest.mark.parametrize("geom", [(2, 3, 6, 8), (1, 5, 32, 32), (1, 5, 20, 32)])
+@pytest.mark.parametrize("path", ["mfma", "valu"])
+def test_epi_attention_vs_masked_mha(vertical, geom, path, monkeypatch):
+    """window predicate == the reference's additive -inf mask (EPIT.py:93-108) inside nn.MultiheadAttention's core; both the MFMA kernel
+    (attn_mfma.hip, default) and the VALU kernels, at a reduced geometry and at EPIT's own (5 x 32 = 160 tokens per sequence; 5 x 20: ragged last tile)"""
     lib = capi.load()
-    B, A, h, w, E, NH = 2, 3, 6, 8, 128, 8
+    if path == "valu":
+        monkeypatch.setenv("LFSR_ATTN", "valu")
+    else:
+        monkeypatch.delenv("LFSR_ATTN", raising=False)
+    (B, A, h, w), E, NH = geom, 128, 8
     npix = B * A * A * h * w
     q, k, v = rnd((npix, E), 7), rnd((npix, E), 8), rnd((npix, E), 9)
     o = torch.empty(npix, E, device="cuda")
@@ -94,6 +101,7 @@ def test_epi_attention_vs_masked_mha(vertical):
     L = A * (w if vertical else h)
     mask = O.epit_gen_mask(A, w if vertical else h, 2 * A, 11, np.float64)
     Q, K, V = to_seq(q), to_seq(k), to_seq(v)
+    assert Q.shape[0] == L
     hd = E // NH
     Qh = Q.reshape(L, -1, hd).transpose(1, 0, 2)
     Kh = K.reshape(L, -1, hd).transpose(1, 0, 2)

@@ -23,12 +23,12 @@ for res in (None, r):
     sel = os.environ.get("LFSR_CONV3X3", "")
     if sel == "":   # F(4x4,3x3) kernel (default): per (chunk, stage) segments, chunk barriers, the epilogue at the head of a pass
         d = dbg.reshape(256, 64).cpu().double()
-        names = (["chunk %d MFMA stream after A" % k for k in range(4)] + ["-"] * 4 + ["At M A + exchange writes"] + ["-"] * 7
+        names = (["chunk %d MFMA stream after A" % k for k in range(4)] + ["-"] * 4 + ["At M A + exchange writes"] + ["-"] + ["B1 wait after chunk %d" % c for c in range(4)] + ["-"] * 2
                  + ["barrier after chunk %d" % c for c in range(4)] + ["exchange barrier"] + ["-"] * 3
                  + ["chunk %d MFMA stream before A" % c for c in range(4)] + ["chunk %d barrier A wait" % c for c in range(4)])
         for c in range(4):
             names += [f"P step {c}: halo registers -> LDS (+ operand request)", f"P step {c}: barrier A wait", f"P step {c}: patch reads + next halo request",
-                      f"P step {c}: input transform + V writes", f"P step {c}: drain a plane", f"P step {c}: chunk barrier wait", "-", "-"]
+                      f"P step {c}: input transform + V writes", f"P step {c}: drain a plane", f"P step {c}: chunk barrier wait (BURST: B1 wait)", f"P step {c}: (BURST) B wait", "-"]
         names[62] = "P: exchange barrier wait"
         tot = d[:, :32].sum(1).mean()
         print(f"residual={res is not None}: mean cycles per block {tot:.0f} ({n_img * 4 / 256:.1f} tiles per block); producer total {d[:, 32:].sum(1).mean():.0f}")
