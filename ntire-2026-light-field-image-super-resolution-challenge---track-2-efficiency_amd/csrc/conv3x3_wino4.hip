@@ -52,6 +52,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                       // VALU count per chunk step sets the pace.  Column pass of the input transform in packed math (v_pk_fma_f32 on column pairs),
                       // per-image buffer descriptors instead of per-slot row bounds checks, per-thread offsets formed once per launch, max-form LeakyReLU.
 #endif
+#ifndef W4_AG
+#define W4_AG 24      // the MFMA group of a chunk at which the consumers join barrier A (producers: halo staged).  The producers' VALU work makes no
+                      // progress beside a streaming MFMA wave anyway, so a late A costs them nothing and the consumers never wait at it
+#endif
+#ifndef W4_LATELOAD
+#define W4_LATELOAD 1 // the producers request the halo two chunks ahead at the END of their step (the consumers are at the chunk barrier by then):
+                      // first-touch misses issued early in a step sit in the CU's memory pipeline in front of the consumers' U fragments
+#endif
 #ifndef W4_BURST
 #define W4_BURST 0    // 1: the producers' input transform (their VALU-dense part) runs in a burst of its own between two barriers, while the consumers
                       // wait: fp32 MFMAs and VALU instructions share the SIMD's FMA lanes, and a VALU instruction issued beside a streaming MFMA wave
@@ -329,8 +337,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     while (true) {
       const int next = tile + 1;
       const bool has_next = next < tile_end;
-      int nimg = -1, ny0 = 0, nx0 = 0;
-      if (has_next) tile_origin(next, nimg, ny0, nx0);
+      // the next tile's origin by stepping (tiles are walked in order: no integer divisions -- ~100 VALU instructions -- per tile)
+      int nimg = img, ny0 = y0, nx0 = x0 + 32;
+      if (nx0 >= p.W) { nx0 = 0; ny0 += 8; if (ny0 >= p.H) { ny0 = 0; nimg += 1; } }
+      if (!has_next) nimg = -1;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         // chunk c + 1 (chunk 0 of the next tile when c == 3): halo registers -> LDS | patch -> transform -> V of the other parity
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
           halo_offsets(ny0, nx0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (!(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
+        if (!W4_LATELOAD && !(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 2);
         if (!(W4_ABL & 2)) transform();
@@ -355,6 +365,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 3);
         drain_plane(c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (W4_LATELOAD && !(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 4);
         LDS_BARRIER();   // (B)
@@ -678,7 +690,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
             const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
             if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
             __builtin_amdgcn_sched_barrier(0);       // (keeps every LDS read two groups ahead of its use)
-            if (W4_HALO && g == 3) { STAMP(24 + c); LDS_BARRIER(); STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
+            if (W4_HALO && g == (W4_LEAN ? W4_AG : 3)) { STAMP(24 + c); LDS_BARRIER(); STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
           }
         }
         STAMP(c);

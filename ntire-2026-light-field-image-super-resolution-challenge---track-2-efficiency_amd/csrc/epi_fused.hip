@@ -12,6 +12,8 @@
 // next stage prefetched into registers while the current one computes.  After the last stage the 32x32 result
 // tile is LeakyReLU'd, transposed through LDS into MFMA A-operand order and multiplied by the 1x1 weights
 // (20 KB, read straight from L1/L2), then scattered by chunk (= PixelShuffle1D) to the A views.
+#include <stdlib.h>
+
 #include "lfsr_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,6 +25,7 @@ constexpr int LINES = 8, LROW = 68, TROW = 36;
 struct EpiArgs {
   const float* X; int x_stride; int x_choff; int x_bytes;   // x_bytes: the operand's true byte span (descriptor extent)
   const float* W1;    // [A*A][32][64]  (tap k, n, c)
+  const float* W1u;   // (A = 5, Winograd form) [5 v'][6 p][32 n][64 c]: U = G g over the five spatial taps of view v' (lfsr_pack_epi_wino)
   const float* W2;    // [32A][32]      (n = chunk*32 + c, k): the 1x1 weights, row-major as packed by lfsr_pack_conv_weight
   float* Y; int y_stride; int choffH; int choffV;
   float* TH; float* TV;   // optional (lines*len, 32): post-LeakyReLU stage-1 activations saved for backward
@@ -215,7 +218,242 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
   }
 }
 
+
+// ---- A = 5, stage 1 in Winograd F(2,5) form ------------------------------------------------------------------------------------------------
+// Stage 1 is a 5-tap 1-D conv along the EPI line over 5 x 64 = 320 input channels: y[t] = sum_{v', dx, c} W[v', dx][n][c] x[v'][t + dx - 2][c].
+// F(2,5) on the points 0, +-1, +-2, inf (the interpolation points -- and therefore Bt -- of the F(4,3) transform of conv3x3_wino4.hip):
+//   Y = At [ sum_{v', c} (G g)[p] . (Bt d)[p] ],   d = the 6 inputs of an output pair, 6 products per 2 outputs instead of 10.
+// One wave = one EPI line = 16 output pairs = the 16 A-rows of v_mfma_f32_16x16x4_f32; N = 32 = two N tiles.  The input transform runs in
+// the MFMA wave itself, on the operand registers: lane (pair j, g) reads its six raw vectors x[2 j + i][16 s + 4 g ..+3] (ds_read_b128),
+// forms Bt d for the four channels at once (packed math: 24 instructions) and has the A operands of 6 p x 4 steps x 2 N tiles = 48 MFMAs;
+// U comes from LDS ([p][n][c] rows of one view per stage).  48 accumulator registers; At in registers; then stage 2 exactly as k_epi_fused.
+// fp32 round-off: the same transform family as the 3x3 convs' F(4x4,3x3), in one dimension only (tools / tests: test_epiconv*).
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+// the fma sequence of conv3x3_wino4.hip's bt6 on channel pairs (v_pk_fma_f32 / v_pk_add_f32)
+__device__ __forceinline__ void bt6v(f32x2w& d0, f32x2w& d1, f32x2w& d2, f32x2w& d3, f32x2w& d4, f32x2w& d5) {
+  const f32x2w m4 = {-4.f, -4.f}, p4 = {4.f, 4.f}, m5 = {-5.f, -5.f}, p2 = {2.f, 2.f}, m2 = {-2.f, -2.f};
+  const f32x2w a = __builtin_elementwise_fma(m4, d2, d4), b = __builtin_elementwise_fma(m4, d1, d3);
+  const f32x2w c = d4 - d2, e = d3 - d1;
+  const f32x2w t0 = __builtin_elementwise_fma(p4, d0, __builtin_elementwise_fma(m5, d2, d4));
+  const f32x2w t5 = __builtin_elementwise_fma(p4, d1, __builtin_elementwise_fma(m5, d3, d5));
+  d0 = t0; d1 = a + b; d2 = a - b; d3 = __builtin_elementwise_fma(p2, e, c); d4 = __builtin_elementwise_fma(m2, e, c); d5 = t5;
+}
+
+__global__ __launch_bounds__(512) void k_epi_wino5(EpiArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int A = 5, PP = 36, pad = 2;
+  float* sA = smem;                              // [LINES][PP][LROW]
+  float* sU = smem + LINES * PP * LROW;          // [6][32][LROW]
+  int* sLine = reinterpret_cast<int*>(sU + 6 * 32 * LROW);
+  float* sW2 = reinterpret_cast<float*>(sLine + LINES + 4);   // [32A][TROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = tid & 15, r16 = tid >> 4;
+  const int half = lane >> 5, l31 = lane & 31, l15 = lane & 15, g = lane >> 4;
+  const int HW = p.H * p.W;
+
+  const bool vert = (int)blockIdx.x >= p.tilesH;
+  const int tile = vert ? blockIdx.x - p.tilesH : blockIdx.x;
+  const int len = vert ? p.H : p.W;
+  const int across = vert ? p.W : p.H;
+  const int nlines = p.B * A * across;
+  const int vstride = vert ? A * HW : HW;
+  const int pstride = vert ? p.W : 1;
+  const int choff = vert ? p.choffV : p.choffH;
+
+  if (tid < LINES) {
+    int ln = tile * LINES + tid;
+    int base = -1;
+    if (ln < nlines) {
+      int q = ln / across, o = ln - q * across;
+      if (!vert) base = q * A * HW + o * p.W;
+      else { int b = q / A, v = q - b * A; base = (b * A * A + v) * HW + o; }
+    }
+    sLine[tid] = base;
+  }
+  {
+    float4 wv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 512 * q;
+      wv[q] = idx < A * 32 * 8 ? reinterpret_cast<const float4*>(p.W2)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 512 * q;
+      if (idx < A * 32 * 8) *reinterpret_cast<float4*>(sW2 + (idx >> 3) * TROW + (idx & 7) * 4) = wv[q];
+    }
+  }
+  __syncthreads();
+
+  constexpr int nvec = LINES * PP;
+  constexpr int EOOB = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W1u), 0, A * 6 * 32 * 64 * 4, 0x00020000);
+  int offA[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int vec = r16 + 32 * i, l = vec < nvec ? vec / PP : 0, t = vec - l * PP - pad;
+    const int base = sLine[l];
+    offA[i] = (vec < nvec && base >= 0 && t >= 0 && t < len) ? ((base + t * pstride) * p.x_stride + p.x_choff + c16 * 4) * 4 : EOOB;
+  }
+  const int offU = (r16 * 64 + c16 * 4) * 4;   // row (p = i, n = r16) of a view's U: + i * 32 * 256 bytes
+  f32x4w ra[9], ru[6];
+  auto prefetch = [&](int vv) {
+    const int sA4 = vv * vstride * p.x_stride * 4, sU4 = vv * 6 * 32 * 64 * 4;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ra[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsX, offA[i], sA4, 0));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ru[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsU, offU + i * 32 * 256, sU4, 0));
+  };
+
+  f32x4w acc[6][2];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { acc[q][0] = f32x4w{0.f, 0.f, 0.f, 0.f}; acc[q][1] = acc[q][0]; }
+
+  const float* aBase = sA + (wave * PP + 2 * l15) * LROW + 4 * g;   // raw vector i of this lane's pair: + i * LROW (+ 16 s)
+  const float* uBase = sU + l15 * LROW + 4 * g;                     // U row (p, 16 nt + n): + (p * 32 + 16 nt) * LROW (+ 16 s)
+
+  prefetch(0);
+#pragma unroll 1
+  for (int vv = 0; vv < A; ++vv) {
+    if (vv > 0) __syncthreads();                    // previous stage fully consumed
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int vec = r16 + 32 * i;
+      if (vec < nvec) *reinterpret_cast<f32x4w*>(sA + vec * LROW + c16 * 4) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4w*>(sU + (i * 32 + r16) * LROW + c16 * 4) = ru[i];
+    __syncthreads();
+    if (vv + 1 < A) prefetch(vv + 1);               // flies under this stage's MFMAs
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x2w dl[6], dh[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const f32x4w t = *reinterpret_cast<const f32x4w*>(aBase + i * LROW + 16 * s);
+        dl[i] = __builtin_shufflevector(t, t, 0, 1);
+        dh[i] = __builtin_shufflevector(t, t, 2, 3);
+      }
+      bt6v(dl[0], dl[1], dl[2], dl[3], dl[4], dl[5]);
+      bt6v(dh[0], dh[1], dh[2], dh[3], dh[4], dh[5]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const f32x4w ub = *reinterpret_cast<const f32x4w*>(uBase + (q * 32 + 16 * nt) * LROW + 16 * s);
+          acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[q].x, ub.x, acc[q][nt], 0, 0, 0);
+          acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dl[q].y, ub.y, acc[q][nt], 0, 0, 0);
+          acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[q].x, ub.z, acc[q][nt], 0, 0, 0);
+          acc[q][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[q].y, ub.w, acc[q][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __syncthreads();                                   // stage area is dead: reuse it for the transposition
+
+  // ---- At: y[2 j] = M0 + M1 + M2 + M3 + M4,  y[2 j + 1] = M1 - M2 + 2 (M3 - M4) + M5;  t = lrelu(y) [pos][32] -> LDS (row stride 36) ----
+  float* sT = sA + wave * 32 * TROW;
+  {
+    float* tsave = vert ? p.TV : p.TH;
+    const bool save = tsave && sLine[wave] >= 0;
+    long long rowbase = 0; int rowstep = 0;
+    if (save) {
+      int ln = tile * LINES + wave;
+      int q = ln / across, o = ln - q * across;
+      // rows of the saved matrix are ordered like the gather-GEMM's stage-1 rows: (b*A+u, y, x) / (b*A+v, y, x)
+      rowbase = vert ? (long long)q * p.H * p.W + o : ((long long)q * p.H + o) * p.W;
+      rowstep = vert ? p.W : 1;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const f32x4w s12 = acc[1][nt] + acc[2][nt], d12 = acc[1][nt] - acc[2][nt], s34 = acc[3][nt] + acc[4][nt], d34 = acc[3][nt] - acc[4][nt];
+      const f32x4w y0 = (acc[0][nt] + s12) + s34;
+      const f32x4w y1 = (d12 + 2.f * d34) + acc[5][nt];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const int pos = 2 * (4 * g + r) + a;
+          float v = a ? y1[r] : y0[r];
+          v = v >= 0.f ? v : v * p.slope;
+          sT[pos * TROW + 16 * nt + l15] = v;
+          if (save && pos < len) tsave[(rowbase + (long long)pos * rowstep) * 32 + 16 * nt + l15] = v;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  float4 fa[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fa[j] = *reinterpret_cast<const float4*>(sT + l31 * TROW + 8 * j + 4 * half);
+
+  const int base = sLine[wave];
+  for (int nt = 0; nt < A; ++nt) {                  // chunk nt = destination view along the EPI's angular axis
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 b = *reinterpret_cast<const float4*>(sW2 + (nt * 32 + l31) * TROW + 8 * j + 4 * half);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].x, b.x, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].y, b.y, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].z, b.z, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j].w, b.w, o, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pos = (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = o[r];
+      v = v >= 0.f ? v : v * p.slope;
+      sT[pos * TROW + l31] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (base >= 0) {
+      const long long dview = (long long)base + (long long)nt * vstride;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pos = (lane >> 3) + 8 * q, c4 = (lane & 7) * 4;
+        if (pos < len)
+          *reinterpret_cast<float4*>(p.Y + (dview + (long long)pos * pstride) * p.y_stride + choff + c4) = *reinterpret_cast<const float4*>(sT + pos * TROW + c4);
+      }
+    }
+  }
+}
+
+// U[v'][p][n][c] = sum_dx G[p][dx] W1[tap A dx + v'][n][c]  (fp64, rounded once), G of F(2,5) on the points 0, +-1, +-2, inf
+__global__ __launch_bounds__(256) void k_pack_epi_wino(const float* __restrict__ w1, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (v', n, c)
+  if (i >= 5 * 32 * 64) return;
+  const int c = i & 63, n = (i >> 6) & 31, v = i >> 11;
+  double gk[5];
+#pragma unroll
+  for (int dx = 0; dx < 5; ++dx) gk[dx] = (double)w1[((5 * dx + v) * 32 + n) * 64 + c];
+  const double G[6][5] = {{1.0 / 4, 0, 0, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3}, {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3}, {0, 0, 0, 0, 1.0}};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    double u = 0.0;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) u += G[q][dx] * gk[dx];
+    out[((v * 6 + q) * 32 + n) * 64 + c] = (float)u;
+  }
+}
+
 }  // namespace
+
+int lfsr_pack_epi_wino(const float* w1_direct_packed, float* out, hipStream_t st) {
+  if (!w1_direct_packed || !out) return LFSR_E_ARG;
+  hipLaunchKernelGGL(k_pack_epi_wino, dim3(40), dim3(256), 0, st, w1_direct_packed, out);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+static size_t epi_wino_smem() { return (size_t)(LINES * 36 * LROW + 6 * 32 * LROW) * 4 + (LINES + 4) * 4 + (size_t)5 * 32 * TROW * 4; }
 
 size_t lfsr_epi_fused_smem(int A) {
   return (size_t)(LINES * (32 + A - 1) * LROW + A * 32 * LROW) * 4 + (LINES + 4) * 4 + (size_t)A * 32 * TROW * 4;
@@ -237,6 +475,7 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_fused<5>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_fused<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_wino5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)epi_wino_smem());
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
@@ -249,7 +488,11 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   p.tilesV = (which & 2) ? (B * A * w + LINES - 1) / LINES : 0;
   int grid = p.tilesH + p.tilesV;
   if (grid <= 0) return LFSR_E_ARG;
-  if (A == 5) hipLaunchKernelGGL(k_epi_fused<5>, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);
+  // A = 5: stage 1 in Winograd F(2,5) form (the pack appended to the direct one by lfsr_pack_conv_weight); LFSR_EPI=direct keeps the direct form (A/B runs)
+  const char* esel = getenv("LFSR_EPI");
+  p.W1u = w1_packed + 25 * 32 * 64;
+  if (A == 5 && !(esel && esel[0] == 'd')) hipLaunchKernelGGL(k_epi_wino5, dim3((unsigned)grid), dim3(512), epi_wino_smem(), st, p);
+  else if (A == 5) hipLaunchKernelGGL(k_epi_fused<5>, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);
   else hipLaunchKernelGGL(k_epi_fused<0>, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;

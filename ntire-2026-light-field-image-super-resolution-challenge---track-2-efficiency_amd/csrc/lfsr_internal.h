@@ -45,6 +45,9 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
 bool lfsr_ang_fused_ok(int A);
 int lfsr_ang_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* t, float* y,
                           int y_stride, int y_choff, int B, int A, int h, int w, float slope, hipStream_t st);
+// epi_fused.hip: Winograd F(2,5) pack of an EPIConv.0 weight (O = 32, C = 64, taps = 25 = 5 x 5): LFSR_EPI_WINO_FLOATS after the direct pack
+#define LFSR_EPI_WINO_FLOATS (5 * 6 * 32 * 64)
+int lfsr_pack_epi_wino(const float* w1_direct_packed, float* out, hipStream_t st);
 // epi_fused.hip  (t_h / t_v: optional (B*A*h*w, 32) buffers receiving the post-LeakyReLU stage-1 activations for backward)
 bool lfsr_epi_fused_ok(int A, int h, int w);
 int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,
