@@ -390,8 +390,9 @@ def bench_infer(args, rank, world, dev, dist):
         # per-class lines: algorithmic bytes (one read of every input + one write of every output, fp32) and flops per launch at this B
         npx = float(M)
         cls_spec = {   # class -> (kernel, bound, bytes, flop)
-            "epiconv": ("k_epi (both EPI passes: 1xA^2 conv 64->32, LReLU, 1x1 32->160, LReLU, PixelShuffle1D; DistgSSR.py:91-97,108)", "mfma",
-                        (64 + 64) * npx * 4, 2 * (0.524e9 + 0.052e9) * B),
+            # executed flops: stage 1 in Winograd F(2,5) form runs 6 products per 2 outputs instead of 10 (x 0.6; LFSR_EPI=direct: x 1.0)
+            "epiconv": ("k_epi_wino5 (both EPI passes: 1xA^2 conv 64->32 in F(2,5) form, LReLU, 1x1 32->160, LReLU, PixelShuffle1D; DistgSSR.py:91-97,108)", "mfma",
+                        (64 + 64) * npx * 4, 2 * (0.524e9 * (1.0 if os.environ.get("LFSR_EPI", "")[:1] == "d" else 0.6) + 0.052e9) * B),
             "pointwise": ("fuse.0 144->64 + LReLU (DistgSSR.py:98-100,109)", "hbm", (144 + 64) * npx * 4, 0.472e9 * B),
             "angconv": ("k_ang_fused (AngConv.0 + LReLU + AngConv.2 + LReLU + PixelShuffle(A); DistgSSR.py:84-90)", "hbm", (64 + 16) * npx * 4, 0.065e9 * B),
             "init_conv": ("k_initconv (SAI2MacPI + 3x3 1->64; DistgSSR.py:22,31-32)", "hbm", (1 + 64) * npx * 4, 0.029e9 * B),

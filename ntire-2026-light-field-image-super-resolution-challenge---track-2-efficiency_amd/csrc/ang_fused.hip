@@ -36,7 +36,25 @@ __global__ __launch_bounds__(512) void k_ang_fused(AngArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
   const int i = lane & 15, kq = lane >> 4;
 
-  {   // W1: 16 float4 per (tap, n) row; all of a thread's loads are issued before its first LDS store (one L2 round trip, not 13)
+  const int ngroups = (M + 15) / 16, gstride = (int)gridDim.x * nwave;
+  const int g0 = (int)blockIdx.x * nwave + wave;
+  const long long tstep = (long long)HW * p.x_stride;
+  float4 fb[2][5][4];   // two register sets, alternated by the (fully unrolled) row loop: no copies, the loads of row u+1 stay in flight
+  // fragment loads of one row of views of group g (macro-pixel m = 16 g + i, view `tap` -> VCL pixel (b*AA + tap)*HW + yx)
+  auto load_row = [&](int g, int u, float4 (*f)[4]) {
+    const int m = g * 16 + i;
+    const bool ok = m < M;
+    const int mb = ok ? m / HW : 0, myx = ok ? m - mb * HW : 0;
+    const float* src = p.X + ((long long)mb * AA * HW + myx) * p.x_stride + p.x_choff + 4 * kq;
+#pragma unroll
+    for (int v = 0; v < 5; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        f[v][j] = (ok && v < p.A) ? *reinterpret_cast<const float4*>(src + (u * p.A + v) * tstep + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  {   // W1: 16 float4 per (tap, n) row; all of a thread's loads are issued before its first LDS store (one L2 round trip, not 13); the
+      // first group's first row of views is requested in between, so its HBM latency runs under the weight staging (at B = 32 a wave owns
+      // exactly one group: the preamble used to sit serially in front of every byte the wave streams)
     float4 wv[13];
 #pragma unroll
     for (int q = 0; q < 13; ++q) {
@@ -49,6 +67,7 @@ __global__ __launch_bounds__(512) void k_ang_fused(AngArgs p) {
       const int idx = tid + q * 512;
       w2v[q] = idx < AA * 64 ? reinterpret_cast<const float4*>(p.W2)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (g0 < ngroups) load_row(g0, 0, fb[0]);
 #pragma unroll
     for (int q = 0; q < 13; ++q) {
       const int idx = tid + q * 512;
@@ -65,31 +84,19 @@ __global__ __launch_bounds__(512) void k_ang_fused(AngArgs p) {
   float* st = sT + wave * 16 * TROW;
   const float* b1 = sW1 + i * W1ROW + 4 * kq;     // + tap * 16 * W1ROW + 16 j
   const float* b2 = sW2 + i * 16 + 4 * kq;        // + view * 256
-  const int ngroups = (M + 15) / 16, gstride = (int)gridDim.x * nwave;
 
-  for (int g = (int)blockIdx.x * nwave + wave; g < ngroups; g += gstride) {
-    // A-fragment source: macro-pixel m = 16 g + i, view `tap` -> VCL pixel (b*AA + tap)*HW + yx
+  for (int g = g0; g < ngroups; g += gstride) {
     const int m = g * 16 + i;
     const bool ok = m < M;
     const int mb = ok ? m / HW : 0, myx = ok ? m - mb * HW : 0;
-    const float* src = p.X + ((long long)mb * AA * HW + myx) * p.x_stride + p.x_choff + 4 * kq;
-    const long long tstep = (long long)HW * p.x_stride;
     // the views are taken A at a time (one row of views): the next A views' fragments (A x 64 B per lane, 20 KB per wave at A = 5)
     // are in flight while the current ones feed the MFMAs -- with 8 such waves a CU keeps ~160 KB of HBM reads outstanding
-    auto load_row = [&](int u, float4 (*f)[4]) {
-#pragma unroll
-      for (int v = 0; v < 5; ++v)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          f[v][j] = (ok && v < p.A) ? *reinterpret_cast<const float4*>(src + (u * p.A + v) * tstep + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    float4 fb[2][5][4];   // two register sets, alternated by the (fully unrolled) row loop: no copies, the loads of row u+1 stay in flight
-    load_row(0, fb[0]);
+    if (g != g0) load_row(g, 0, fb[0]);
     f32x4a acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
       if (u >= p.A) break;
-      if (u + 1 < p.A) load_row(u + 1, fb[(u + 1) & 1]);
+      if (u + 1 < p.A) load_row(g, u + 1, fb[(u + 1) & 1]);
 #pragma unroll
       for (int v = 0; v < 5; ++v) {
         if (v >= p.A) break;

@@ -263,16 +263,39 @@ __global__ __launch_bounds__(512) void k_epi_wino5(EpiArgs p) {
   const int pstride = vert ? p.W : 1;
   const int choff = vert ? p.choffV : p.choffH;
 
-  if (tid < LINES) {
-    int ln = tile * LINES + tid;
-    int base = -1;
-    if (ln < nlines) {
-      int q = ln / across, o = ln - q * across;
-      if (!vert) base = q * A * HW + o * p.W;
-      else { int b = q / A, v = q - b * A; base = (b * A * A + v) * HW + o; }
-    }
-    sLine[tid] = base;
+  auto line_base = [&](int l) -> int {               // first pixel of EPI line l of this tile, -1 beyond the tensor
+    const int ln = tile * LINES + l;
+    if (ln >= nlines) return -1;
+    const int q = ln / across, o = ln - q * across;
+    if (!vert) return q * A * HW + o * p.W;
+    const int b = q / A, v = q - b * A;
+    return (b * A * A + v) * HW + o;
+  };
+  if (tid < LINES) sLine[tid] = line_base(tid);
+
+  // stage-0 operands are requested FIRST (line bases in registers, not through LDS), so their HBM latency runs under the staging of the
+  // 1x1 weights below: a block's prologue is otherwise serial (1280 blocks = 5 rounds per launch)
+  constexpr int nvec = LINES * PP;
+  constexpr int EOOB = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W1u), 0, A * 6 * 32 * 64 * 4, 0x00020000);
+  int offA[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int vec = r16 + 32 * i, l = vec < nvec ? vec / PP : 0, t = vec - l * PP - pad;
+    const int base = line_base(l);
+    offA[i] = (vec < nvec && base >= 0 && t >= 0 && t < len) ? ((base + t * pstride) * p.x_stride + p.x_choff + c16 * 4) * 4 : EOOB;
   }
+  const int offU = (r16 * 64 + c16 * 4) * 4;   // row (p = i, n = r16) of a view's U: + i * 32 * 256 bytes
+  f32x4w ra[9], ru[6];
+  auto prefetch = [&](int vv) {
+    const int sA4 = vv * vstride * p.x_stride * 4, sU4 = vv * 6 * 32 * 64 * 4;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ra[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsX, offA[i], sA4, 0));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ru[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsU, offU + i * 32 * 256, sU4, 0));
+  };
+  prefetch(0);
   {
     float4 wv[3];
 #pragma unroll
@@ -286,28 +309,6 @@ __global__ __launch_bounds__(512) void k_epi_wino5(EpiArgs p) {
       if (idx < A * 32 * 8) *reinterpret_cast<float4*>(sW2 + (idx >> 3) * TROW + (idx & 7) * 4) = wv[q];
     }
   }
-  __syncthreads();
-
-  constexpr int nvec = LINES * PP;
-  constexpr int EOOB = (int)0x80000000u;
-  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W1u), 0, A * 6 * 32 * 64 * 4, 0x00020000);
-  int offA[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int vec = r16 + 32 * i, l = vec < nvec ? vec / PP : 0, t = vec - l * PP - pad;
-    const int base = sLine[l];
-    offA[i] = (vec < nvec && base >= 0 && t >= 0 && t < len) ? ((base + t * pstride) * p.x_stride + p.x_choff + c16 * 4) * 4 : EOOB;
-  }
-  const int offU = (r16 * 64 + c16 * 4) * 4;   // row (p = i, n = r16) of a view's U: + i * 32 * 256 bytes
-  f32x4w ra[9], ru[6];
-  auto prefetch = [&](int vv) {
-    const int sA4 = vv * vstride * p.x_stride * 4, sU4 = vv * 6 * 32 * 64 * 4;   // wave-uniform
-#pragma unroll
-    for (int i = 0; i < 9; ++i) ra[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsX, offA[i], sA4, 0));
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ru[i] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsU, offU + i * 32 * 256, sU4, 0));
-  };
 
   f32x4w acc[6][2];
 #pragma unroll
@@ -316,7 +317,6 @@ __global__ __launch_bounds__(512) void k_epi_wino5(EpiArgs p) {
   const float* aBase = sA + (wave * PP + 2 * l15) * LROW + 4 * g;   // raw vector i of this lane's pair: + i * LROW (+ 16 s)
   const float* uBase = sU + l15 * LROW + 4 * g;                     // U row (p, 16 nt + n): + (p * 32 + 16 nt) * LROW (+ 16 s)
 
-  prefetch(0);
 #pragma unroll 1
   for (int vv = 0; vv < A; ++vv) {
     if (vv > 0) __syncthreads();                    // previous stage fully consumed

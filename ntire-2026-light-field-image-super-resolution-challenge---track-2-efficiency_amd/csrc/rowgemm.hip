@@ -101,50 +101,48 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         float4 b = *reinterpret_cast<const float4*>(bRow + t * 32 * LR + 8 * j);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        // operands swapped (A = the weight rows, B = the x rows): D[channel][row m], so a lane holds runs of four consecutive CHANNELS of
+        // one row -- the epilogue stores 16 B per lane with no transposition
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc[t], 0, 0, 0);
       }
     }
-    // epilogue straight from the accumulators: a store instruction covers 32 consecutive channels of two rows
-    const long long m0 = tile * BMR;
-    if (!p.R1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int n = n0 + ng * (NB / 2) + t * 32 + l31;
-          if (n >= p.N) continue;
-          float v = acc[t][r];
-          if (p.bias) v += p.bias[n];
-          v = v >= 0.f ? v : v * p.slope;
-          p.Y[m * p.y_stride + p.y_choff + n] = v;
-        }
-      }
-    } else {
-      // with a residual operand: its loads of a column tile are issued back to back before the first use (per element they
-      // were waited for one by one)
+    // epilogue straight from the accumulators: register group q of tile t = channels n0' + 32 t + 8 q + 4 half .. + 3 of row m0 + 32 rg + l31:
+    // one 16-B store per group (bias / residual as 16-B loads, all of a tile's residual loads issued before the first use)
+    const long long m = tile * BMR + rg * 32 + l31;
+    if (m < p.M) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int n = n0 + ng * (NB / 2) + t * 32 + l31;
-        const bool ncol = n < p.N;
-        const float bs = (p.bias && ncol) ? p.bias[n] : 0.f;
-        float rv[16];
+        const int nb = n0 + ng * (NB / 2) + t * 32 + 4 * half;
+        float4 rv[4];
+        if (p.R1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          rv[r] = (ncol && m < p.M) ? p.R1[m * p.r1_stride + p.r1_choff + n] : 0.f;
+          for (int q = 0; q < 4; ++q) {
+            const int n = nb + 8 * q;
+            rv[q] = n + 3 < p.N ? *reinterpret_cast<const float4*>(p.R1 + m * p.r1_stride + p.r1_choff + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long long m = m0 + rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (m >= p.M || !ncol) continue;
-          float v = acc[t][r] + bs;
-          v = v >= 0.f ? v : v * p.slope;
-          p.Y[m * p.y_stride + p.y_choff + n] = v + rv[r];
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q;
+          if (n >= p.N) continue;
+          float v[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+          if (n + 3 < p.N) {
+            if (p.bias) { const float4 bs = *reinterpret_cast<const float4*>(p.bias + n); v[0] += bs.x; v[1] += bs.y; v[2] += bs.z; v[3] += bs.w; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+            if (p.R1) { v[0] += rv[q].x; v[1] += rv[q].y; v[2] += rv[q].z; v[3] += rv[q].w; }
+            *reinterpret_cast<float4*>(p.Y + m * p.y_stride + p.y_choff + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {   // ragged N (not a multiple of 4): element by element
+            for (int k = 0; k < 4 && n + k < p.N; ++k) {
+              float x = v[k] + (p.bias ? p.bias[n + k] : 0.f);
+              x = x >= 0.f ? x : x * p.slope;
+              if (p.R1) x += p.R1[m * p.r1_stride + p.r1_choff + n + k];
+              p.Y[m * p.y_stride + p.y_choff + n + k] = x;
+            }
+          }
         }
       }
     }
@@ -180,6 +178,9 @@ int launch_rowgemm(const RowGemmArgs& p, hipStream_t st) {
 int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
                         const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st) {
   if ((x_stride | x_choff) & 3 || N % 32) return LFSR_E_ARG;
+  // the epilogue stores / loads 16 B per lane: every operand row and channel offset a multiple of four floats, 16-B aligned bases
+  if ((y_stride | y_choff) & 3 || (res && ((res_stride | res_choff) & 3))) return LFSR_E_ARG;
+  if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)res | (uintptr_t)bias) & 15) return LFSR_E_ARG;
   if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x (caller falls back to the gather-GEMM)
   RowGemmArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.bias = bias; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;

@@ -98,6 +98,7 @@ class get_model(nn.Module):
                                       nn.PixelShuffle(self.factor), nn.Conv2d(channels, 1, kernel_size=1, bias=False))
         self._rt = None
         self._rt_version = None
+        self._pack_graph, self._pack_ptrs, self._pack_eager_count = None, None, 0
         self._spans = None
         self.grad_bucket = None      # flat fp32 gradient bucket filled by the HIP backward (state_dict order)
 
@@ -109,9 +110,30 @@ class get_model(nn.Module):
             self._spans = {k: self._rt.param_span(k) for k, _ in self.named_parameters()}
         ver = (device, tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if ver != self._rt_version:   # (re)pack after load_state_dict / .to() / an optimizer step
-            self._rt.load_state(self.state_dict().items(), device)
+            self._repack(device)
             self._rt_version = ver
         return self._rt
+
+    def _repack(self, device):
+        """Hand the current parameter values to the HIP library.  An optimizer step changes values, not addresses: the ~400 small pack
+        launches (137 parameters x their layouts) are then replayed from ONE captured graph instead of being re-issued through 137 ctypes
+        calls (LFSR_PACK_GRAPH=0 disables; any change of a parameter's address falls back to the eager path and re-captures)."""
+        import os
+        ptrs = (device, tuple(p.data_ptr() for p in self.parameters()))
+        if self._pack_graph is not None and ptrs == self._pack_ptrs:
+            self._pack_graph.replay()
+            return
+        self._pack_graph = None
+        self._rt.load_state(self.state_dict().items(), device)
+        self._pack_eager_count = self._pack_eager_count + 1 if ptrs == self._pack_ptrs else 1
+        self._pack_ptrs = ptrs
+        if self._pack_eager_count >= 2 and os.environ.get("LFSR_PACK_GRAPH", "1") != "0" and all(
+                p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters()):
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._rt.load_state(self.state_dict().items(), device)
+            self._pack_graph = g
 
     def invalidate_packed(self):
         """Force a repack of the HIP library's weight copies at the next forward.  The runtime notices parameter updates through

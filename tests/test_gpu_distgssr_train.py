@@ -305,3 +305,26 @@ def test_amp_loop_shape_gradscaler():
         assert float((p - q).abs().max()) <= 2 * 2e-4 + 1e-6, k      # AdamW's first updates ~ lr * sign(g): round-off level gradients may differ in sign
     diff = sum(int(((p - q).abs() > 2e-6).sum()) for p, q in zip(nets[0].parameters(), nets[1].parameters()))
     assert diff / sum(p.numel() for p in nets[0].parameters()) < 1e-3
+
+
+def test_graph_replayed_repack_equals_eager(monkeypatch):
+    """After an optimizer step only parameter VALUES change: the weight repack is replayed from one captured graph (model/SR/DistgSSR.py:_repack).
+    Five steps with the replayed repack equal five steps with the eager one, bit for bit."""
+    from lfsr_amd.train_step import train_step
+    A, h, w, s, B = 3, 6, 8, 2, 2
+    case, sd, x, _ = model_case("DistgSSR", "a3h6w8s2")
+    label = torch.from_numpy(synth_input((B, 1, A * h * s, A * w * s), seed=2)).cuda()
+    xa = torch.from_numpy(x).cuda()
+    M = load_plugin()
+    runs = []
+    for graph in ("1", "0"):
+        monkeypatch.setenv("LFSR_PACK_GRAPH", graph)
+        net = build(M, A, s, sd)
+        opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
+        crit = M.get_loss(None)
+        losses = [float(train_step(net, crit, opt, xa, label)[0]) for _ in range(5)]
+        assert (net._pack_graph is not None) == (graph == "1")
+        runs.append((losses, [p.detach().clone() for p in net.parameters()]))
+    assert runs[0][0] == runs[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+    assert runs[0][0][-1] < runs[0][0][0]      # and it trains
