@@ -468,7 +468,9 @@ int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st) {
   if (!direct_packed || !out) return LFSR_E_ARG;
   hipLaunchKernelGGL(k_pack_wino, dim3(16), dim3(256), 0, st, direct_packed, out);
   LFSR_CHECK_LAUNCH();
-  return lfsr_pack_wino4(direct_packed, out + LFSR_CONV3_WINO2_FLOATS, st);
+  int rc = lfsr_pack_wino4(direct_packed, out + LFSR_CONV3_WINO2_FLOATS, st);
+  if (rc) return rc;
+  return lfsr_pack_wino4s(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, st);
 }
 
 // w_wino: the Winograd-domain pack (lfsr_pack_wino); w_direct: the [9][64][64] pack, used by the channel-split tail launch.
@@ -476,9 +478,16 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
                              int n_img, int h, int w, float slope, hipStream_t st) {
-  {   // default: the F(4x4,3x3) kernel (conv3x3_wino4.hip); LFSR_CONV3X3=wino2 keeps this one (A/B runs), as do operands >= 1 GiB
+  {   // F(4x4,3x3): the symmetric-wave kernel (conv3x3_wino4s.hip, LFSR_CONV3X3=wino4s) or the specialised-wave one (conv3x3_wino4.hip);
+      // LFSR_CONV3X3=wino2 keeps this file's F(2x2,3x3) kernel (A/B runs), as do operands the F(4x4) launchers do not cover
     const char* sel = getenv("LFSR_CONV3X3");
-    if (!(sel && sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o' && sel[4] == '2')) {
+    const bool is_w = sel && sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o';
+    if (is_w && sel[4] == '4' && sel[5] == 's') {
+      const int rc = lfsr_conv3x3_wino4s_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, y, y_stride, y_choff,
+                                                r1, r1_stride, r1_choff, r2, r2_stride, r2_choff, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);
+      if (rc != LFSR_E_ARG) return rc;
+    }
+    if (!(is_w && sel[4] == '2')) {
       const int rc = lfsr_conv3x3_wino4_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS, y, y_stride, y_choff, r1, r1_stride, r1_choff,
                                                r2, r2_stride, r2_choff, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);
       if (rc != LFSR_E_ARG) return rc;

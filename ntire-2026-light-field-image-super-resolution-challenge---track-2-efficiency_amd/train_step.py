@@ -7,13 +7,36 @@ import torch
 import torch.distributed as dist
 
 
+_CAPI_COMM = {}
+
+
+def _capi_comm(group):
+    """RCCL communicator created through the C ABI (lfsr_comm_init): rank 0's unique id travels over the existing process group."""
+    key = id(group)
+    if key not in _CAPI_COMM:
+        from lfsr_amd import capi
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def exchange(raw):
+            box = [raw if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            return box[0]
+        _CAPI_COMM[key] = capi.RcclComm(world, rank, exchange)
+    return _CAPI_COMM[key]
+
+
 def allreduce_bucket(bucket, group=None):
-    """Average a flat gradient bucket over the data-parallel group in ONE collective."""
+    """Average a flat gradient bucket over the data-parallel group in ONE collective: torch.distributed's backend ("nccl" = RCCL on ROCm;
+    gloo in the CPU tests) by default, or -- LFSR_ALLREDUCE=capi, GPU buckets only -- lfsr_allreduce of the C ABI on the current stream."""
     if not (dist.is_available() and dist.is_initialized()):
         return bucket
     world = dist.get_world_size(group)
     if world > 1:
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+        import os
+        if os.environ.get("LFSR_ALLREDUCE", "") == "capi" and bucket.is_cuda:
+            _capi_comm(group).allreduce_(bucket)
+        else:
+            dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
         bucket.div_(world)
     return bucket
 

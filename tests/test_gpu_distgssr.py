@@ -80,15 +80,18 @@ def test_packed_conv_weight_carries_winograd_copy():
     """lfsr_pack_conv_weight(64,64,3,3) = direct [9][64][64] pack followed by U = G g Gt in the fragment order of the kernel"""
     wt = rnd((64, 64, 3, 3), 21, 0.05)
     wp = capi.pack_conv_weight(dev(wt)).cpu().numpy()
-    assert wp.size == 9 * 64 * 64 + 16 * 64 * 64 + 36 * 64 * 64
+    assert wp.size == 9 * 64 * 64 + 16 * 64 * 64 + 36 * 64 * 64 + 36 * 64 * 64
     direct = wt.reshape(64, 64, 9).transpose(2, 0, 1).reshape(-1)           # [tap][n][k]
     assert np.array_equal(wp[:9 * 64 * 64], direct)
     ref = O.winograd_pack(wt)
     w2 = wp[9 * 64 * 64:25 * 64 * 64]
     assert np.abs(w2 - ref).max() <= 1e-9 and np.mean(w2 == ref) > 0.999   # fp64 compute, one rounding
     ref4 = O.winograd4_pack(wt)                                             # F(4x4,3x3) copy (conv3x3_wino4.hip)
-    w4 = wp[25 * 64 * 64:]
+    w4 = wp[25 * 64 * 64:61 * 64 * 64]
     assert np.abs(w4 - ref4).max() <= 1e-8 and np.mean(w4 == ref4) > 0.99
+    # the same U once more in the per-wave record order of the symmetric-wave kernel (conv3x3_wino4s.hip): a permutation of the values above
+    w4s = wp[61 * 64 * 64:]
+    assert w4s.size == 36 * 64 * 64 and np.abs(np.sort(w4s) - np.sort(w4)).max() <= 1e-8    # (fp64 contraction may differ in the last bit)
 
 
 def test_conv3x3_tail_and_fallback_kernels(monkeypatch):
