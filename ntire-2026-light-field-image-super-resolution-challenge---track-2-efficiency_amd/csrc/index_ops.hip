@@ -41,9 +41,13 @@ __global__ __launch_bounds__(256) void k_sai_macpi(const T* __restrict__ in, T* 
 // ---- a1 / a2, vectorised: 16-B global accesses on both sides, permutation through LDS ---------------------------------
 // One block = G consecutive y of one (b,c) plane = A*G input rows <-> A*G output rows (row length A*w floats, A*w % 4 == 0).
 // LDS holds the SAI-side image [u][g][A*w]; the MacPI side element (g, u, x*A+v) is LDS[u][g][v*w+x].
-template <int TO_MACPI>
-__global__ __launch_bounds__(256) void k_sai_macpi_lds(const float* __restrict__ in, float* __restrict__ out, int A, int h, int w, int G) {
+// AT = the angular resolution when it is a compile-time constant (5: BASELINE; divisions by A become multiplies), 0 = run-time A.
+// All of a thread's loads are issued before its first LDS store (up to 8 x 16 B in flight per thread, 32 KB per block); the (row, column)
+// of a thread's k-th vector is stepped, not divided out.
+template <int TO_MACPI, int AT>
+__global__ __launch_bounds__(256) void k_sai_macpi_lds(const float* __restrict__ in, float* __restrict__ out, int A_rt, int h, int w, int G) {
   extern __shared__ float sm[];
+  const int A = AT ? AT : A_rt;
   const int Wd = A * w, Hd = A * h, W4 = Wd / 4;
   const int ygroups = (h + G - 1) / G;
   const long long plane = blockIdx.x / ygroups;
@@ -52,54 +56,56 @@ __global__ __launch_bounds__(256) void k_sai_macpi_lds(const float* __restrict__
   const float* pin = in + plane * Hd * Wd;
   float* pout = out + plane * Hd * Wd;
   const int nvec = A * g_n * W4;    // float4 per side
-  if (TO_MACPI) {
-    // 4 loads in flight per thread before the first LDS store (a load-then-store loop waits for each load in turn)
-    for (int i0 = threadIdx.x; i0 < nvec; i0 += 1024) {      // SAI rows (u*h + y0+g) -> LDS [u][g][:]
-      float4 v[4];
+  const int dr = 256 / W4, dc = 256 - dr * W4;   // vector i + 256 sits dr rows and dc columns further (with carry)
+  constexpr int NV = 8;                          // vectors per thread and pass
+  for (int base = 0; base < nvec; base += 256 * NV) {
+    // global side A (source): rows in the order they are stored in; LDS image [u][g][:] = the SAI-side rows
+    float4 v[NV];
+    int c4 = (base + threadIdx.x) % W4, r = (base + threadIdx.x) / W4;
+    int cc[NV], rr[NV];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + 256 * q, ii = i < nvec ? i : 0;
-        const int c4 = ii % W4, r = ii / W4, g = r % g_n, u = r / g_n;
-        v[q] = *reinterpret_cast<const float4*>(pin + (long long)(u * h + y0 + g) * Wd + c4 * 4);
-      }
+    for (int q = 0; q < NV; ++q) {
+      cc[q] = c4; rr[q] = r;
+      const bool ok = base + threadIdx.x + 256 * q < nvec;
+      // TO_MACPI: source row r = u * g_n + g -> SAI row u*h + y0 + g;  else: source row r = g * A + u -> MacPI row (y0+g)*A + u
+      int srow;
+      if (TO_MACPI) { const int u = r / g_n, g = r - u * g_n; srow = u * h + y0 + g; }
+      else srow = y0 * A + r;
+      v[q] = ok ? *reinterpret_cast<const float4*>(pin + (long long)srow * Wd + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      c4 += dc; r += dr;
+      if (c4 >= W4) { c4 -= W4; r += 1; }
+    }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + 256 * q;
-        if (i < nvec) { const int c4 = i % W4, r = i / W4, g = r % g_n, u = r / g_n; *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = v[q]; }
+    for (int q = 0; q < NV; ++q) {
+      if (base + threadIdx.x + 256 * q < nvec) {
+        int u, g;
+        if (TO_MACPI) { u = rr[q] / g_n; g = rr[q] - u * g_n; } else { g = rr[q] / A; u = rr[q] - g * A; }
+        *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + cc[q] * 4) = v[q];
       }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nvec; i += 256) {           // MacPI rows ((y0+g)*A + u), 4 consecutive columns
-      int c4 = i % W4, r = i / W4, u = r % A, g = r / A;
-      const float* row = sm + (u * G + g) * Wd;
+  }
+  __syncthreads();
+  {
+    int c4 = threadIdx.x % W4, r = threadIdx.x / W4;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
       float o[4];
+      long long drow;
+      if (TO_MACPI) {           // MacPI rows ((y0+g)*A + u), 4 consecutive columns: element (x*A + v) = LDS[u][g][v*w + x]
+        const int g = r / A, u = r - g * A;
+        const float* row = sm + (u * G + g) * Wd;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { int col = c4 * 4 + e, x = col / A, v = col - x * A; o[e] = row[v * w + x]; }
-      *reinterpret_cast<float4*>(pout + (long long)((y0 + g) * A + u) * Wd + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-  } else {
-    for (int i0 = threadIdx.x; i0 < nvec; i0 += 1024) {      // MacPI rows -> LDS [u][g][x*A+v]
-      float4 v[4];
+        for (int e = 0; e < 4; ++e) { const int col = c4 * 4 + e, x = col / A, vv = col - x * A; o[e] = row[vv * w + x]; }
+        drow = (long long)(y0 + g) * A + u;
+      } else {                  // SAI rows (u*h + y0+g): element (v*w + x) = LDS[u][g][x*A + v]
+        const int u = r / g_n, g = r - u * g_n;
+        const float* row = sm + (u * G + g) * Wd;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + 256 * q, ii = i < nvec ? i : 0;
-        const int c4 = ii % W4, r = ii / W4, u = r % A, g = r / A;
-        v[q] = *reinterpret_cast<const float4*>(pin + (long long)((y0 + g) * A + u) * Wd + c4 * 4);
+        for (int e = 0; e < 4; ++e) { const int col = c4 * 4 + e, vv = col / w, x = col - vv * w; o[e] = row[x * A + vv]; }
+        drow = (long long)u * h + y0 + g;
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + 256 * q;
-        if (i < nvec) { const int c4 = i % W4, r = i / W4, u = r % A, g = r / A; *reinterpret_cast<float4*>(sm + (u * G + g) * Wd + c4 * 4) = v[q]; }
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nvec; i += 256) {           // SAI rows (u*h + y0+g)
-      int c4 = i % W4, r = i / W4, g = r % g_n, u = r / g_n;
-      const float* row = sm + (u * G + g) * Wd;
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { int col = c4 * 4 + e, v = col / w, x = col - v * w; o[e] = row[x * A + v]; }
-      *reinterpret_cast<float4*>(pout + (long long)(u * h + y0 + g) * Wd + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(pout + drow * Wd + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      c4 += dc; r += dr;
+      if (c4 >= W4) { c4 -= W4; r += 1; }
     }
   }
 }
@@ -301,7 +307,8 @@ int lfsr_sai2macpi(const void* in, void* out, int B, int C, int A, int h, int w,
     while (G > 1 && (size_t)A * G * A * w * 4 > 48 * 1024) G >>= 1;
     if ((size_t)A * G * A * w * 4 <= 64 * 1024) {
       long long nblk = (long long)B * C * ((h + G - 1) / G);
-      hipLaunchKernelGGL((k_sai_macpi_lds<1>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
+      if (A == 5) hipLaunchKernelGGL((k_sai_macpi_lds<1, 5>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
+      else hipLaunchKernelGGL((k_sai_macpi_lds<1, 0>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
       LFSR_CHECK_LAUNCH();
       return LFSR_OK;
     }
@@ -324,7 +331,8 @@ int lfsr_macpi2sai(const void* in, void* out, int B, int C, int A, int h, int w,
     while (G > 1 && (size_t)A * G * A * w * 4 > 48 * 1024) G >>= 1;
     if ((size_t)A * G * A * w * 4 <= 64 * 1024) {
       long long nblk = (long long)B * C * ((h + G - 1) / G);
-      hipLaunchKernelGGL((k_sai_macpi_lds<0>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
+      if (A == 5) hipLaunchKernelGGL((k_sai_macpi_lds<0, 5>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
+      else hipLaunchKernelGGL((k_sai_macpi_lds<0, 0>), dim3((unsigned)nblk), dim3(256), (size_t)A * G * A * w * 4, lfsr_stream(stream), (const float*)in, (float*)out, A, h, w, G);
       LFSR_CHECK_LAUNCH();
       return LFSR_OK;
     }

@@ -6,6 +6,8 @@
 // MFMAs; one A image in LDS (rows padded by 4 floats: conflict-free ds_read_b128), two barriers per tile.
 // Against the generic gather-GEMM this removes the per-stage weight re-staging (a 128-row block re-read the whole panel) and
 // the 64-float K staging granularity.
+#include <stdlib.h>
+
 #include "gemm_gather_kernel.h"
 #include "lfsr_internal.h"
 
@@ -188,9 +190,14 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
   // 64-row tiles, 64-column panels: <= 76 KB of LDS -> two 256-thread blocks per CU, which is what keeps HBM loads in flight
   // while the other block runs its MFMAs
   if (N % 64) return LFSR_E_ARG;
+  // N a multiple of 128 (the transformer projections): 128-row x 128-column tiles, one 512-thread block per CU, each wave 32 rows x 64
+  // columns -- X is streamed once per 128 output columns instead of once per 64, a B fragment feeds two MFMA column tiles, and a tile's
+  // barriers / prefetch / epilogue are paid per 128 MFMAs of a wave instead of per 64 (LFSR_ROWGEMM=64 keeps the 64 x 64 form: A/B runs)
+  const char* rsel = getenv("LFSR_ROWGEMM");
+  const bool wide = N % 128 == 0 && !(rsel && rsel[0] == '6');
   switch (K) {
-    case 64: return launch_rowgemm<64, 64, 64>(p, st);
-    case 128: return launch_rowgemm<128, 64, 64>(p, st);
+    case 64: return wide ? launch_rowgemm<64, 128, 128>(p, st) : launch_rowgemm<64, 64, 64>(p, st);
+    case 128: return wide ? launch_rowgemm<128, 128, 128>(p, st) : launch_rowgemm<128, 64, 64>(p, st);
     case 144: return launch_rowgemm<144, 64, 64>(p, st);
     default: return LFSR_E_ARG;
   }

@@ -36,18 +36,24 @@ def test_layernorm():
         assert np.abs(y.cpu().numpy() - ref).max() < 1e-5
 
 
-@pytest.mark.parametrize("cin,N,slope", [(64, 128, 1.0), (128, 256, 0.0), (256, 128, 1.0), (128, 64, 0.2), (128, 96, 1.0)])
-def test_linear(cin, N, slope):
+@pytest.mark.parametrize("M", [777, 5003])      # 777: gather-GEMM; 5003 (ragged against 64- and 128-row tiles): the row-streaming GEMM, 64x64 and 128x128 tiles
+@pytest.mark.parametrize("cin,N,slope", [(64, 128, 1.0), (128, 256, 0.0), (256, 128, 1.0), (128, 64, 0.2), (128, 96, 1.0), (128, 128, 1.0), (144, 64, 0.1)])
+def test_linear(cin, N, slope, M, monkeypatch):
+    if cin == 144 and M < 2048:
+        pytest.skip("K = 144 (fuse.0) exists in the row-streaming GEMM only; lfsr_pointwise_fwd covers it at small M")
     lib = capi.load()
-    M = 777
-    x, w, r = rnd((M, cin), 4), rnd((N, cin), 5, 0.1), rnd((M, N), 6)
-    y = torch.empty(M, N, device="cuda")
-    xd, rd, wp = dev(x), dev(r), capi.pack_conv_weight(dev(w.reshape(N, cin, 1, 1)))
-    capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xd), cin, 0, cin, capi.dev_ptr(wp), None,
-                                   capi.dev_ptr(rd), N, 0, capi.dev_ptr(y), N, 0, M, N, slope, capi.stream_ptr()), "linear")
+    x, w, r, b = rnd((M, cin), 4), rnd((N, cin), 5, 0.1), rnd((M, N), 6), rnd((N,), 7)
+    xd, rd, bd, wp = dev(x), dev(r), dev(b), capi.pack_conv_weight(dev(w.reshape(N, cin, 1, 1)))
     z = x.astype(np.float64) @ w.astype(np.float64).T
-    ref = np.where(z >= 0, z, z * slope) + r
-    assert np.abs(y.cpu().numpy() - ref).max() < ATOL
+    for sel in ("", "64"):       # LFSR_ROWGEMM=64 keeps the 64 x 64 tiles where the 128 x 128 form is the default
+        monkeypatch.setenv("LFSR_ROWGEMM", sel)
+        for use_r, use_b in ((True, False), (False, True), (False, False)):
+            y = torch.full((M, N), float("nan"), device="cuda")
+            capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xd), cin, 0, cin, capi.dev_ptr(wp), capi.dev_ptr(bd) if use_b else None,
+                                           capi.dev_ptr(rd) if use_r else None, N, 0, capi.dev_ptr(y), N, 0, M, N, slope, capi.stream_ptr()), "linear")
+            zz = z + (b if use_b else 0.0)
+            ref = np.where(zz >= 0, zz, zz * slope) + (r if use_r else 0.0)
+            assert np.abs(y.cpu().numpy() - ref).max() < ATOL, (sel, use_r, use_b)
 
 
 @pytest.mark.parametrize("K1,H,M", [(128, 256, 777), (64, 128, 2100), (128, 256, 70000)])

@@ -11,7 +11,13 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    return {k: (sum(v.values()) / len(v), len(v)) for k, v in acc.items()}
+    # bench.py also runs a few B = 1 forwards (its batch-split check): keep the full-size launches only (>= half the largest value of the kernel)
+    out = {}
+    for k, v in acc.items():
+        vals = list(v.values())
+        big = [x for x in vals if x >= 0.5 * max(vals)] or vals
+        out[k] = (sum(big) / len(big), len(big))
+    return out
 
 
 fetch, write, stats, out = sys.argv[1:5]
@@ -40,6 +46,17 @@ for r in csv.DictReader(open(stats)):
     if KEY in r["Name"]:
         tot_ns += float(r["TotalDurationNs"]); calls += int(r["Calls"])
 res["rocprof_avg_us_per_op"] = tot_ns / max(calls, 1) / 1000.0
+res["rocprof_avg_note"] = "mean over ALL launches of the --kernel-trace --stats pass, the B = 1 launches of bench.py's batch-split check included (2 x 53 of them per run)"
+import os
+trace = stats.replace("kernel_stats", "kernel_trace")
+if os.path.exists(trace):   # full-size launches only (grid of the B = 32 forward), from the same pass's kernel trace
+    du = defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if KEY in r["Kernel_Name"]:
+            du[int(r["Grid_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    full = du[max(du)]
+    res["rocprof_avg_us_per_full_size_op"] = sum(full) / len(full) / 1000.0
+    res["rocprof_full_size_launches"] = len(full)
 json.dump(res, open(out, "w"), indent=1)
 if len(sys.argv) > 5:   # optional: every kernel's HBM bytes per launch (same correction) -> profiles/r01_pmc_traffic.json
     allk = {}
