@@ -470,7 +470,9 @@ int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st) {
   LFSR_CHECK_LAUNCH();
   int rc = lfsr_pack_wino4(direct_packed, out + LFSR_CONV3_WINO2_FLOATS, st);
   if (rc) return rc;
-  return lfsr_pack_wino4s(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, st);
+  rc = lfsr_pack_wino4s(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, st);
+  if (rc) return rc;
+  return lfsr_pack_wino4b(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS, st);
 }
 
 // w_wino: the Winograd-domain pack (lfsr_pack_wino); w_direct: the [9][64][64] pack, used by the channel-split tail launch.
@@ -482,6 +484,11 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
       // LFSR_CONV3X3=wino2 keeps this file's F(2x2,3x3) kernel (A/B runs), as do operands the F(4x4) launchers do not cover
     const char* sel = getenv("LFSR_CONV3X3");
     const bool is_w = sel && sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o';
+    if (is_w && sel[4] == '4' && sel[5] == 'b') {
+      const int rc = lfsr_conv3x3_wino4b_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS, y, y_stride, y_choff,
+                                                r1, r1_stride, r1_choff, r2, r2_stride, r2_choff, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);
+      if (rc != LFSR_E_ARG) return rc;
+    }
     if (is_w && sel[4] == '4' && sel[5] == 's') {
       const int rc = lfsr_conv3x3_wino4s_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, y, y_stride, y_choff,
                                                 r1, r1_stride, r1_choff, r2, r2_stride, r2_choff, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);

@@ -37,6 +37,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define W4_URING 12   // depth of the U fragment ring (16-B fragments in flight per wave); must divide 144
 #endif
 
+#ifndef W4_LDPOL
+#define W4_LDPOL 0    // cache-policy bits of the producers' streamed loads (gfx94x/950 buffer instructions: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef W4_STPOL
+#define W4_STPOL 0    // ... and of the output stores
+#endif
 #ifndef W4_SWAP
 #define W4_SWAP 0     // 1: waves 0..3 produce and waves 4..7 consume (which half of a workgroup is dispatched first decides VALU-issue arbitration)
 #endif
@@ -118,11 +124,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, in
 __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// the producers' streamed operands (halo, epilogue operands: each byte is read about once) and the output, with a cache-policy field of their own
+__device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, W4_LDPOL));
+}
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, int voff, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, 0, W4_STPOL);
 }
 
 // one 6-vector of the input transform: t = Bt d  (12 operations, integer coefficients: exact products)
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     f32x4 hv0[6], hv1[6];
     auto halo_load = [&](f32x4 (&hv)[6], __amdgpu_buffer_rsrc_t rs, int chunk) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) hv[i] = bload4(rs, hx[i], chunk * 64);
+      for (int i = 0; i < 6; ++i) hv[i] = bload4s(rs, hx[i], chunk * 64);
     };
     float* hdst[6];
 #pragma unroll
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         const bool bad = ragged_w && pcol0 + dcol[i] >= p.W;
         const int offy = pY[i] + rowoff * (p.y_stride * 4), offe = pE[i] + rowoff * (e_stride * 4);
         oy[i] = bad ? OOB : offy;
-        if (HAS_E) e[i] = bload4(rsEp, bad ? OOB : offe, 0);
+        if (HAS_E) e[i] = bload4s(rsEp, bad ? OOB : offe, 0);
       }
     };
     auto drain_plane = [&](int a) {
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         } else if (HAS_E) {
           v += e[i];
         }
-        if (HAS_L) { const int offl = pL[i] + rowoff * (l_stride * 4); v += bload4(rsLp, oy[i] == OOB ? OOB : offl, 0); }
+        if (HAS_L) { const int offl = pL[i] + rowoff * (l_stride * 4); v += bload4s(rsLp, oy[i] == OOB ? OOB : offl, 0); }
         if (!(W4_ABL & 32) || i == 0) bstore4(rsYp, oy[i], v);
       }
     };

@@ -31,7 +31,14 @@ int lfsr_conv3x3_halo_tail_launch(const float* x, int x_stride, int x_choff, con
 #define LFSR_CONV3_WINO4_FLOATS (36 * 64 * 64)
 // ... followed by the same F(4x4,3x3) U in the per-wave record order of the symmetric-wave kernel, conv3x3_wino4s.hip
 #define LFSR_CONV3_WINO4S_FLOATS (36 * 64 * 64)
-#define LFSR_CONV3_WINO_FLOATS (LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS)
+// ... followed by the F(4x4,3x3) U split into three bf16 terms per weight (6 B instead of 4), conv3x3_wino4b.hip
+#define LFSR_CONV3_WINO4B_FLOATS (54 * 64 * 64)
+#define LFSR_CONV3_WINO_FLOATS (LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS + LFSR_CONV3_WINO4B_FLOATS)
+int lfsr_pack_wino4b(const float* direct_packed, float* out, hipStream_t st);
+int lfsr_conv3x3_wino4b_launch(const float* x, int x_stride, int x_choff, const float* w_wino4b, float* y, int y_stride, int y_choff,
+                               const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
+                               const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                               int n_img, int h, int w, float slope, hipStream_t st);
 int lfsr_pack_wino4s(const float* direct_packed, float* out, hipStream_t st);
 int lfsr_conv3x3_wino4s_launch(const float* x, int x_stride, int x_choff, const float* w_wino4s, float* y, int y_stride, int y_choff,
                                const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,

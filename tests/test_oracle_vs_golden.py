@@ -236,3 +236,23 @@ def test_winograd4_roundoff_through_the_whole_network():
     finally:
         P.F.conv2d = orig
     assert np.abs(y - ref).max() < 1e-5 and psnr(y, ref) > 120.0
+
+
+def test_split_bf16_products():
+    """the arithmetic of conv3x3_wino4b.hip restated in numpy: fp32 operands as three bf16 terms (input: truncation, exact; weights: round to
+    nearest), six of the nine cross products -> closer to the fp64 dot product than an fp32 dot product is, and the split itself is exact"""
+    rng = np.random.default_rng(0)
+    def trunc(x): return (x.astype(np.float32).view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    def rne(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32).view(np.float32)
+    def split3(x, f):
+        a = f(x); r = (x - a).astype(np.float32); b = f(r); r2 = (r - b).astype(np.float32); return a, b, f(r2)
+    x = (rng.standard_normal((500, 64)) * 3).astype(np.float32); w = (rng.uniform(-1, 1, (64, 64)) / 24).astype(np.float32)
+    x0, x1, x2 = split3(x, trunc); w0, w1, w2 = split3(w, rne)
+    assert np.array_equal(x0.astype(np.float64) + x1 + x2, x.astype(np.float64))
+    assert np.array_equal(w0.astype(np.float64) + w1 + w2, w.astype(np.float64))
+    ref = x.astype(np.float64) @ w.astype(np.float64)
+    six = sum(a.astype(np.float64) @ b.astype(np.float64) for a, b in ((x0, w0), (x1, w1), (x1, w0), (x0, w1), (x0, w2), (x2, w0)))
+    e6, e32 = np.abs(six - ref).max() / np.abs(ref).max(), np.abs((x @ w) - ref).max() / np.abs(ref).max()
+    assert e6 < 1e-7 and e6 < e32
