@@ -158,6 +158,11 @@ int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st) {
   p.Mk = g.Mk; p.mk_stride = g.mk_stride; p.mk_choff = g.mk_choff; p.mk_slope = g.mk_slope;
   p.M = g.M; p.N = g.N; p.Npad = npad32(g.N); p.A = g.A; p.AA = g.A * g.A; p.H = g.h; p.W = g.w; p.ntaps = g.ntaps; p.CH = g.CH; p.slope = 1.0f;
   if ((g.x_stride | g.x_choff) & 3) return LFSR_E_ARG;
+  // fuse.0 dgrad (64 -> 144, masked by the saved concat buffer): the row-streaming kernel (LFSR_NO_ROWGEMM keeps the gather-GEMM: A/B runs)
+  if (g.in_mode == LFSR_IN_SAME && g.out_mode == LFSR_OUT_SAME && g.cin == 64 && g.N == 144 && g.ntaps == 1 && !g.R1 && g.M >= 2048 && !getenv("LFSR_NO_ROWGEMM")) {
+    const int rc = lfsr_rowgemm_dgrad144_launch(g.X, g.x_stride, g.x_choff, g.Wp, g.Mk, g.mk_stride, g.mk_choff, g.mk_slope, g.Y, g.y_stride, g.y_choff, g.M, st);
+    if (rc != LFSR_E_ARG) return rc;
+  }
 #define BG(IM, OM, CI, NT) if (g.in_mode == IM && g.out_mode == OM && g.cin == CI && p.Npad % (32 * NT) == 0) return launch_gemm<IM, OM, CI, NT>(p, st);
   BG(IN_SAME, OUT_SAME, 64, 1)      // fuse.0 dgrad (64 -> 144)
   BG(IN_ANG, OUT_SAME, 16, 1)       // AngConv.2 dgrad (A*A x 16 -> 16)
@@ -177,9 +182,11 @@ int lfsr_conv3x3_bwd_data(const float* dy, int dy_stride, int dy_choff, const fl
   const bool al = !((dy_stride | dy_choff | dx_stride | dx_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!mk || !((mk_stride | mk_choff) & 3));
   {
     const char* sel = getenv("LFSR_CONV3X3");
-    if (al && !(sel && (sel[0] == 'h' || sel[0] == 'g')))
-      return lfsr_conv3x3_wino_launch(dy, dy_stride, dy_choff, wT_packed + LFSR_CONV3_DIRECT_FLOATS, wT_packed, dx, dx_stride, dx_choff, r1, r1_stride, r1_choff,
-                                      nullptr, 0, 0, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, 1.0f, st);
+    if (al && !(sel && (sel[0] == 'h' || sel[0] == 'g'))) {
+      const int rc = lfsr_conv3x3_wino_launch(dy, dy_stride, dy_choff, wT_packed + LFSR_CONV3_DIRECT_FLOATS, wT_packed, dx, dx_stride, dx_choff, r1, r1_stride, r1_choff,
+                                              nullptr, 0, 0, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, 1.0f, st);
+      if (rc != LFSR_E_ARG) return rc;   // (E_ARG: a geometry the Winograd launchers do not cover -> the direct kernel)
+    }
   }
   if (al)
     return lfsr_conv3x3_halo_launch(dy, dy_stride, dy_choff, wT_packed, dx, dx_stride, dx_choff, r1, r1_stride, r1_choff, nullptr, 0, 0,

@@ -464,16 +464,32 @@ __global__ __launch_bounds__(256) void k_pack_wino(const float* __restrict__ dir
 
 }  // namespace
 
-int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st) {
-  if (!direct_packed || !out) return LFSR_E_ARG;
-  hipLaunchKernelGGL(k_pack_wino, dim3(16), dim3(256), 0, st, direct_packed, out);
-  LFSR_CHECK_LAUNCH();
-  int rc = lfsr_pack_wino4(direct_packed, out + LFSR_CONV3_WINO2_FLOATS, st);
-  if (rc) return rc;
-  rc = lfsr_pack_wino4s(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, st);
-  if (rc) return rc;
-  return lfsr_pack_wino4b(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS, st);
+int lfsr_conv3_variant_mask() {
+  const char* sel = getenv("LFSR_CONV3X3");
+  if (!sel) return LFSR_W_WINO4;
+  if (sel[0] == 'h' || sel[0] == 'g') return 0;                              // direct kernels: the direct pack only
+  if (sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o') {
+    if (sel[4] == '2') return LFSR_W_WINO2;
+    if (sel[4] == '4' && sel[5] == 's') return LFSR_W_WINO4S | LFSR_W_WINO4;   // (+ the kernel an uncovered geometry falls back to)
+    if (sel[4] == '4' && sel[5] == 'b') return LFSR_W_WINO4B | LFSR_W_WINO4;
+  }
+  return LFSR_W_WINO4;
 }
+
+int lfsr_pack_wino_m(const float* direct_packed, float* out, int mask, hipStream_t st) {
+  if (!direct_packed || !out) return LFSR_E_ARG;
+  int rc = LFSR_OK;
+  if (mask & LFSR_W_WINO2) {
+    hipLaunchKernelGGL(k_pack_wino, dim3(16), dim3(256), 0, st, direct_packed, out);
+    LFSR_CHECK_LAUNCH();
+  }
+  if (!rc && (mask & LFSR_W_WINO4)) rc = lfsr_pack_wino4(direct_packed, out + LFSR_CONV3_WINO2_FLOATS, st);
+  if (!rc && (mask & LFSR_W_WINO4S)) rc = lfsr_pack_wino4s(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, st);
+  if (!rc && (mask & LFSR_W_WINO4B)) rc = lfsr_pack_wino4b(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS, st);
+  return rc;
+}
+
+int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st) { return lfsr_pack_wino_m(direct_packed, out, LFSR_W_ALL, st); }
 
 // w_wino: the Winograd-domain pack (lfsr_pack_wino); w_direct: the [9][64][64] pack, used by the channel-split tail launch.
 int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const float* w_wino, const float* w_direct, float* y, int y_stride, int y_choff,
@@ -500,6 +516,9 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
       if (rc != LFSR_E_ARG) return rc;
     }
   }
+  // this file's F(2x2) kernel runs only when LFSR_CONV3X3 selects it (the runtimes pack only the selected copies): operands the F(4x4)
+  // launchers do not cover (1 GiB and more) go to the callers' direct 9-tap kernel
+  if (!(lfsr_conv3_variant_mask() & LFSR_W_WINO2)) return LFSR_E_ARG;
   static std::atomic<bool> attr_set[64];
   static std::atomic<int> cus[64];
   int dev = 0;

@@ -740,14 +740,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #endif
 }
 
-// U = G g G^t per (n, k) from the direct pack [tap][n][k] -> [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4]
-__global__ __launch_bounds__(256) void k_pack_wino4(const float* __restrict__ direct, float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;   // (n, k)
-  if (i >= 64 * 64) return;
-  const int n = i >> 6, k = i & 63;
-  double g[3][3];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)direct[(t * 64 + n) * 64 + k];
+// U = G g G^t per (n, k) -> [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4]
+__device__ __forceinline__ void emit_wino4(const double (&g)[3][3], int n, int k, float* __restrict__ out) {
   const double G[6][3] = {{1.0 / 4, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
   double tmp[6][3];
@@ -767,7 +761,43 @@ __global__ __launch_bounds__(256) void k_pack_wino4(const float* __restrict__ di
     }
 }
 
+// ... from the direct pack [tap][n][k]
+__global__ __launch_bounds__(256) void k_pack_wino4(const float* __restrict__ direct, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (n, k)
+  if (i >= 64 * 64) return;
+  const int n = i >> 6, k = i & 63;
+  double g[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)direct[(t * 64 + n) * 64 + k];
+  emit_wino4(g, n, k, out);
+}
+
+// ... from the raw (O = 64, C = 64, 3, 3) weight, writing the direct pack [tap][n][k] as well: one launch per weight where the training
+// step's repack used two.  TR: the transposed, tap-flipped form the data gradient reads (n = the forward's input channel, k = its output channel)
+template <bool TR>
+__global__ __launch_bounds__(256) void k_pack_conv3_raw(const float* __restrict__ w, float* __restrict__ direct, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (n, k)
+  if (i >= 64 * 64) return;
+  const int n = i >> 6, k = i & 63;
+  double g[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float v = TR ? w[(k * 64 + n) * 9 + (8 - t)] : w[(n * 64 + k) * 9 + t];
+    direct[(t * 64 + n) * 64 + k] = v;
+    g[t / 3][t % 3] = (double)v;
+  }
+  emit_wino4(g, n, k, out);
+}
+
 }  // namespace
+
+int lfsr_pack_conv3_raw_wino4(const float* w_raw, float* direct_out, float* wino4_out, int transposed, hipStream_t st) {
+  if (!w_raw || !direct_out || !wino4_out) return LFSR_E_ARG;
+  if (transposed) hipLaunchKernelGGL(k_pack_conv3_raw<true>, dim3(16), dim3(256), 0, st, w_raw, direct_out, wino4_out);
+  else hipLaunchKernelGGL(k_pack_conv3_raw<false>, dim3(16), dim3(256), 0, st, w_raw, direct_out, wino4_out);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
 
 int lfsr_pack_wino4(const float* direct_packed, float* out, hipStream_t st) {
   if (!direct_packed || !out) return LFSR_E_ARG;

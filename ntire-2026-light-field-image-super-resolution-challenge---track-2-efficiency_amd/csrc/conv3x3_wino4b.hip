@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4b(Wino4bArgs p) {
 #pragma unroll
         for (int i = 0; i < G; ++i) if (W4B_OPS & 8) mfma16(acc[pos0 + i], u32x2{u1[i].x, u1[i].y}, v2[cur][i]);
 #pragma unroll
-        for (int i = 0; i < G; ++i) if (W4B_U2 && (W4B_OPS & 16)) mfma16(acc[pos0 + i], u2[i], u32x2{va[cur][i].x, va[cur][i].y});
+        for (int i = 0; i < G; ++i) if ((W4B_U2 != 0) & ((W4B_OPS & 16) != 0)) mfma16(acc[pos0 + i], u2[i], u32x2{va[cur][i].x, va[cur][i].y});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < G; ++i) {

@@ -152,10 +152,11 @@ int lfsr_distgssr_load_param(lfsr_distgssr* c, const char* key, const float* dat
     hipError_t e = hipMemcpyAsync(c->packed + sl.off, data, numel * sizeof(float), hipMemcpyDeviceToDevice, lfsr_stream(stream));
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
   } else {
-    int rc = lfsr_pack_conv_weight(data, c->packed + sl.off, sl.O, sl.C, sl.T, sl.perm, sl.ch, stream);
+    const int vmask = lfsr_conv3_variant_mask();   // only the Winograd-domain copies the selected 3x3 kernel reads (this runs once per weight and training step)
+    int rc = lfsr_pack_conv_weight_m(data, c->packed + sl.off, sl.O, sl.C, sl.T, sl.perm, sl.ch, vmask, stream);
     if (rc) return rc;
     float* tdst = c->packed + sl.offT;
-    if (sl.kindT == 1) rc = lfsr_pack_weight_T(data, tdst, sl.O, sl.C, sl.T, 1, lfsr_stream(stream));
+    if (sl.kindT == 1) rc = lfsr_pack_weight_T_m(data, tdst, sl.O, sl.C, sl.T, 1, vmask, lfsr_stream(stream));
     if (sl.kindT == 2) rc = lfsr_pack_weight_T(data, tdst, sl.O, sl.C, sl.T, 0, lfsr_stream(stream));
     if (sl.kindT == 3) rc = lfsr_pack_weight_chunkT(data, tdst, sl.O, sl.C, 16, 1, lfsr_stream(stream));
     if (sl.kindT == 4) rc = lfsr_pack_weight_chunkT(data, tdst, sl.O, sl.C, 32, 0, lfsr_stream(stream));

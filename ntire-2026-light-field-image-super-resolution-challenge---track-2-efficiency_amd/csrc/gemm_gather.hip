@@ -176,15 +176,25 @@ size_t lfsr_packed_weight_floats(int O, int C, int taps) {
 }
 
 int lfsr_pack_conv_weight(const float* w, float* packed, int O, int C, int taps, int perm, int ch, void* stream) {
+  return lfsr_pack_conv_weight_m(w, packed, O, C, taps, perm, ch, LFSR_W_ALL, stream);
+}
+
+}  // extern "C"
+
+int lfsr_pack_conv_weight_m(const float* w, float* packed, int O, int C, int taps, int perm, int ch, int mask, void* stream) {
   if (!w || !packed || O <= 0 || C <= 0 || taps <= 0 || (perm != 0 && perm != 1)) return LFSR_E_ARG;
   if (perm == 1 && (ch <= 0 || O % ch != 0)) return LFSR_E_ARG;
+  if (O == 64 && C == 64 && taps == 9 && perm == 0 && mask == LFSR_W_WINO4)   // the runtimes' lean repack: one launch per weight
+    return lfsr_pack_conv3_raw_wino4(w, packed, packed + LFSR_CONV3_DIRECT_FLOATS + LFSR_CONV3_WINO2_FLOATS, 0, lfsr_stream(stream));
   long long total = (long long)taps * npad32(O) * C;
   hipLaunchKernelGGL(k_pack_weight, dim3(lfsr_blocks(total, 256)), dim3(256), 0, lfsr_stream(stream), w, packed, O, C, taps, npad32(O), perm, ch);
   LFSR_CHECK_LAUNCH();
-  if (O == 64 && C == 64 && taps == 9 && perm == 0) return lfsr_pack_wino(packed, packed + LFSR_CONV3_DIRECT_FLOATS, lfsr_stream(stream));
+  if (O == 64 && C == 64 && taps == 9 && perm == 0) return lfsr_pack_wino_m(packed, packed + LFSR_CONV3_DIRECT_FLOATS, mask, lfsr_stream(stream));
   if (O == 32 && C == 64 && taps == 25 && perm == 0) return lfsr_pack_epi_wino(packed, packed + 25 * 32 * 64, lfsr_stream(stream));
   return LFSR_OK;
 }
+
+extern "C" {
 
 int lfsr_conv3x3_fwd(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
                      const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
@@ -199,9 +209,11 @@ int lfsr_conv3x3_fwd(const float* x, int x_stride, int x_choff, const float* w_p
     const bool force_v1 = sel && sel[0] == 'g';
     const bool force_halo = sel && sel[0] == 'h';
     const bool al = !((y_stride | y_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!r2 || !((r2_stride | r2_choff) & 3));
-    if (al && !force_v1 && !force_halo)
-      return lfsr_conv3x3_wino_launch(x, x_stride, x_choff, w_packed + LFSR_CONV3_DIRECT_FLOATS, w_packed, y, y_stride, y_choff, r1, r1_stride, r1_choff,
-                                      r2, r2_stride, r2_choff, nullptr, 0, 0, 1.0f, n_img, h, w, slope, lfsr_stream(stream));
+    if (al && !force_v1 && !force_halo) {
+      const int rc = lfsr_conv3x3_wino_launch(x, x_stride, x_choff, w_packed + LFSR_CONV3_DIRECT_FLOATS, w_packed, y, y_stride, y_choff, r1, r1_stride, r1_choff,
+                                              r2, r2_stride, r2_choff, nullptr, 0, 0, 1.0f, n_img, h, w, slope, lfsr_stream(stream));
+      if (rc != LFSR_E_ARG) return rc;   // (E_ARG: a geometry the Winograd launchers do not cover -> the direct kernel)
+    }
     if (al && !force_v1)
       return lfsr_conv3x3_halo_launch(x, x_stride, x_choff, w_packed, y, y_stride, y_choff, r1, r1_stride, r1_choff, r2, r2_stride, r2_choff,
                                       nullptr, 0, 0, 1.0f, n_img, h, w, slope, lfsr_stream(stream));

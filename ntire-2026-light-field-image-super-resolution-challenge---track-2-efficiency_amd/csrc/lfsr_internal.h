@@ -44,7 +44,16 @@ int lfsr_conv3x3_wino4s_launch(const float* x, int x_stride, int x_choff, const 
                                const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                                const float* mk, int mk_stride, int mk_choff, float mk_slope,
                                int n_img, int h, int w, float slope, hipStream_t st);
-int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st);   // both packs
+int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st);   // every Winograd-domain copy (the operator-level pack)
+// ... or only the copies in `mask` (LFSR_W_WINO2 | LFSR_W_WINO4 | LFSR_W_WINO4S | LFSR_W_WINO4B).  The model runtimes repack every weight each
+// training step and write only what the selected 3x3 kernel reads: lfsr_conv3_variant_mask() = the copies LFSR_CONV3X3 selects (default: wino4).
+// The selection is read when weights are packed AND when a conv is launched: set it before loading a model.
+enum { LFSR_W_WINO2 = 1, LFSR_W_WINO4 = 2, LFSR_W_WINO4S = 4, LFSR_W_WINO4B = 8, LFSR_W_ALL = 15 };
+int lfsr_conv3_variant_mask();
+int lfsr_pack_conv3_raw_wino4(const float* w_raw, float* direct_out, float* wino4_out, int transposed, hipStream_t st);   // direct + F(4x4) copies in one launch
+int lfsr_pack_wino_m(const float* direct_packed, float* out, int mask, hipStream_t st);
+int lfsr_pack_conv_weight_m(const float* w, float* packed, int O, int C, int taps, int perm, int ch, int mask, void* stream);
+int lfsr_pack_weight_T_m(const float* w, float* out, int O, int C, int T, int flip, int mask, hipStream_t st);
 int lfsr_pack_wino4(const float* direct_packed, float* out, hipStream_t st);
 // conv3x3_wino4.hip: F(4x4,3x3) form; LFSR_E_ARG = geometry not covered (operands of 1 GiB and more)
 int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const float* w_wino4, float* y, int y_stride, int y_choff,
@@ -94,6 +103,8 @@ int lfsr_add_inplace(float* a, const float* b, long long n, hipStream_t st);   /
 int lfsr_pack_weight_chunkT(const float* w, float* out, int O, int C, int ch, int perm, hipStream_t st);
 
 // rowgemm.hip: persistent row-streaming GEMM with LDS-resident weights; LFSR_E_ARG = shape not covered (use the gather-GEMM)
+int lfsr_rowgemm_dgrad144_launch(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                                 float* dx, int dx_stride, int dx_choff, long long M, hipStream_t st);
 int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
                         const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st);
 

@@ -18,6 +18,7 @@ struct RowGemmArgs {
   const float* Wp;       // [N rows][K] (packed, k contiguous)
   const float* bias;
   const float* R1; int r1_stride; int r1_choff;
+  const float* Mk; int mk_stride; int mk_choff; float mk_slope;   // backward: v *= (Mk > 0 ? 1 : mk_slope), the LeakyReLU' mask of a saved activation
   float* Y; int y_stride; int y_choff;
   long long M; int N;
   float slope;
@@ -136,12 +137,17 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
             if (p.R1) { v[0] += rv[q].x; v[1] += rv[q].y; v[2] += rv[q].z; v[3] += rv[q].w; }
+            if (p.Mk) {
+              const float4 mk = *reinterpret_cast<const float4*>(p.Mk + m * p.mk_stride + p.mk_choff + n);
+              v[0] *= mk.x > 0.f ? 1.f : p.mk_slope; v[1] *= mk.y > 0.f ? 1.f : p.mk_slope; v[2] *= mk.z > 0.f ? 1.f : p.mk_slope; v[3] *= mk.w > 0.f ? 1.f : p.mk_slope;
+            }
             *reinterpret_cast<float4*>(p.Y + m * p.y_stride + p.y_choff + n) = make_float4(v[0], v[1], v[2], v[3]);
           } else {   // ragged N (not a multiple of 4): element by element
             for (int k = 0; k < 4 && n + k < p.N; ++k) {
               float x = v[k] + (p.bias ? p.bias[n + k] : 0.f);
               x = x >= 0.f ? x : x * p.slope;
               if (p.R1) x += p.R1[m * p.r1_stride + p.r1_choff + n + k];
+              if (p.Mk) x *= p.Mk[m * p.mk_stride + p.mk_choff + n + k] > 0.f ? 1.f : p.mk_slope;
               p.Y[m * p.y_stride + p.y_choff + n + k] = x;
             }
           }
@@ -177,6 +183,19 @@ int launch_rowgemm(const RowGemmArgs& p, hipStream_t st) {
 }  // namespace
 
 // returns LFSR_E_ARG when the shape is not covered (caller falls back to the gather-GEMM)
+// the data gradient of a 64-output 1x1 conv whose input has N = 144 channels (DistgSSR fuse.0: dCAT = (dF W) . lrelu'(CAT)): one 192-column
+// panel (the weight rows beyond N are zero-filled, stores beyond N are skipped), X streamed once, the mask applied in the epilogue
+int lfsr_rowgemm_dgrad144_launch(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                                 float* dx, int dx_stride, int dx_choff, long long M, hipStream_t st) {
+  if ((dy_stride | dy_choff | dx_stride | dx_choff) & 3 || (mk && ((mk_stride | mk_choff) & 3))) return LFSR_E_ARG;
+  if (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)mk | (uintptr_t)wT_packed) & 15) return LFSR_E_ARG;
+  if (M * (long long)dy_stride * 4 >= (1LL << 31) || M * (long long)dx_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  RowGemmArgs p{};
+  p.X = dy; p.x_stride = dy_stride; p.x_choff = dy_choff; p.Wp = wT_packed; p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
+  p.Y = dx; p.y_stride = dx_stride; p.y_choff = dx_choff; p.M = M; p.N = 144; p.slope = 1.0f;
+  return launch_rowgemm<64, 192, 64>(p, st);
+}
+
 int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
                         const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st) {
   if ((x_stride | x_choff) & 3 || N % 32) return LFSR_E_ARG;
@@ -190,11 +209,12 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
   // 64-row tiles, 64-column panels: <= 76 KB of LDS -> two 256-thread blocks per CU, which is what keeps HBM loads in flight
   // while the other block runs its MFMAs
   if (N % 64) return LFSR_E_ARG;
-  // N a multiple of 128 (the transformer projections): 128-row x 128-column tiles, one 512-thread block per CU, each wave 32 rows x 64
-  // columns -- X is streamed once per 128 output columns instead of once per 64, a B fragment feeds two MFMA column tiles, and a tile's
-  // barriers / prefetch / epilogue are paid per 128 MFMAs of a wave instead of per 64 (LFSR_ROWGEMM=64 keeps the 64 x 64 form: A/B runs)
+  // LFSR_ROWGEMM=128 (N a multiple of 128: the transformer projections): 128-row x 128-column tiles, one 512-thread block per CU, each wave 32 rows
+  // x 64 columns -- X streamed once per 128 output columns, a B fragment feeding two MFMA column tiles.  Measured on EPIT (B = 8, two runs each in
+  // one call, gpurun_out/r2/bench11_epit*.json): 637-639 patches/s against 659-660 for the 64 x 64 form -- one block per CU hides less HBM latency
+  // than two; the 64 x 64 form stays the default
   const char* rsel = getenv("LFSR_ROWGEMM");
-  const bool wide = N % 128 == 0 && !(rsel && rsel[0] == '6');
+  const bool wide = N % 128 == 0 && rsel && rsel[0] == '1';
   switch (K) {
     case 64: return wide ? launch_rowgemm<64, 128, 128>(p, st) : launch_rowgemm<64, 64, 64>(p, st);
     case 128: return wide ? launch_rowgemm<128, 128, 128>(p, st) : launch_rowgemm<128, 64, 64>(p, st);

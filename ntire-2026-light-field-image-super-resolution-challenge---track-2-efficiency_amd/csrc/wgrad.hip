@@ -346,12 +346,18 @@ int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, 
 }
 
 int lfsr_pack_weight_T(const float* w, float* out, int O, int C, int T, int flip, hipStream_t st) {
+  return lfsr_pack_weight_T_m(w, out, O, C, T, flip, LFSR_W_ALL, st);
+}
+
+int lfsr_pack_weight_T_m(const float* w, float* out, int O, int C, int T, int flip, int mask, hipStream_t st) {
   if (!w || !out || O <= 0 || C <= 0 || T <= 0) return LFSR_E_ARG;
+  if (O == 64 && C == 64 && T == 9 && flip == 1 && mask == LFSR_W_WINO4)   // the runtimes' lean repack: one launch per weight
+    return lfsr_pack_conv3_raw_wino4(w, out, out + LFSR_CONV3_DIRECT_FLOATS + LFSR_CONV3_WINO2_FLOATS, 1, st);
   long long total = (long long)T * npad32(C) * O;
   unsigned grid = lfsr_blocks(total, 256);
   if (grid > 4096) grid = 4096;
   hipLaunchKernelGGL(k_pack_weight_T, dim3(grid), dim3(256), 0, st, w, out, O, C, T, npad32(C), flip);
   LFSR_CHECK_LAUNCH();
-  if (O == 64 && C == 64 && T == 9 && flip == 1) return lfsr_pack_wino(out, out + LFSR_CONV3_DIRECT_FLOATS, st);   // dgrad runs the Winograd kernel too
+  if (O == 64 && C == 64 && T == 9 && flip == 1) return lfsr_pack_wino_m(out, out + LFSR_CONV3_DIRECT_FLOATS, mask, st);   // dgrad runs the Winograd kernel too
   return LFSR_OK;
 }

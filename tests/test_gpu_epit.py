@@ -45,7 +45,7 @@ def test_linear(cin, N, slope, M, monkeypatch):
     x, w, r, b = rnd((M, cin), 4), rnd((N, cin), 5, 0.1), rnd((M, N), 6), rnd((N,), 7)
     xd, rd, bd, wp = dev(x), dev(r), dev(b), capi.pack_conv_weight(dev(w.reshape(N, cin, 1, 1)))
     z = x.astype(np.float64) @ w.astype(np.float64).T
-    for sel in ("", "64"):       # LFSR_ROWGEMM=64 keeps the 64 x 64 tiles where the 128 x 128 form is the default
+    for sel in ("", "128"):      # LFSR_ROWGEMM=128 selects the 128 x 128 tiles where N allows (the 64 x 64 form is the default)
         monkeypatch.setenv("LFSR_ROWGEMM", sel)
         for use_r, use_b in ((True, False), (False, True), (False, False)):
             y = torch.full((M, N), float("nan"), device="cuda")
