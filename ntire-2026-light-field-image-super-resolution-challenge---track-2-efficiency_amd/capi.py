@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblfsr_hip.so")
+LIB_PATH = os.environ.get("LFSR_HIP_LIB") or os.path.join(_HERE, "liblfsr_hip.so")   # (LFSR_HIP_LIB: a diagnostic / A-B build of the same library)
 
 c_p = C.c_void_p
 c_i = C.c_int

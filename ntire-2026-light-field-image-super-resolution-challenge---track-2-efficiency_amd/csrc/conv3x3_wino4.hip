@@ -41,7 +41,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define W4_LDPOL 0    // cache-policy bits of the producers' streamed loads (gfx94x/950 buffer instructions: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
 #ifndef W4_STPOL
-#define W4_STPOL 0    // ... and of the output stores
+#define W4_STPOL (LFSR_NT_STORES ? 2 : 0)    // ... and of the output stores: nt (see lfsr_store_stream in lfsr_common.h)
 #endif
 #ifndef W4_SWAP
 #define W4_SWAP 0     // 1: waves 0..3 produce and waves 4..7 consume (which half of a workgroup is dispatched first decides VALU-issue arbitration)
