@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-check", action="store_true",
+                    help="skip the B = 1 re-runs of the batch-independence check (profiling passes: keeps every launch of a kernel the same size)")
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: 32 infer, 8 train / epit / lft)")
     ap.add_argument("--workload", choices=["infer", "train", "epit", "lft"], default="infer",
                     help="infer = configs[1] (headline, default); train = configs[3]: DistgSSR x4 fp32 train step, batch 8 per GPU, RCCL bucket "
@@ -352,8 +354,10 @@ def bench_infer(args, rank, world, dev, dist):
     if rank == 0:
         assert torch.isfinite(y).all()
         # B = 32 forward == the same patches run one at a time (batch independence of the path; bit-equal expected)
-        y1 = torch.cat([rt.forward(x[i:i + 1]) for i in (0, B - 1)], 0)
-        batch_split_max_abs_diff = float((y1 - rt.forward(x)[[0, B - 1]]).abs().max())
+        batch_split_max_abs_diff = None
+        if not args.no_split_check:
+            y1 = torch.cat([rt.forward(x[i:i + 1]) for i in (0, B - 1)], 0)
+            batch_split_max_abs_diff = float((y1 - rt.forward(x)[[0, B - 1]]).abs().max())
         M = B * A * A * H * W
         conv_ms, conv_n = prof["conv3x3"]
         conv_s = conv_ms / max(conv_n, 1) * 1e-3
