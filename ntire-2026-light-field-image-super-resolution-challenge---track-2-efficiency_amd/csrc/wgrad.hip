@@ -207,6 +207,173 @@ __global__ __launch_bounds__(512) void k_wgrad_conv3_halo(Wgrad3Args p) {
   }
 }
 
+// ---- 3x3 conv weight gradient in Winograd form: the adjoint of F(2x2, 3x3) -------------------------------------------------------
+//   forward   Y = At [ (G g Gt) . (Bt d B) ] A            per 2x2 output tile, d = its 4x4 input patch
+//   adjoint   dU[a][b] += (A dY At)[a][b] . (Bt d B)[a][b]  summed over tiles and images,   dW = Gt dU G
+// 16 products per 2x2 outputs and channel pair instead of 36: 2.25x fewer MFMA flops than the direct form above (coefficients 0, +-1, +-1/2:
+// exact transforms, well-conditioned).  The 16 position-GEMMs dU[p][n][k] += sum_tiles dY'[p][tile][n] V[p][tile][k] have the TILE index as
+// the MFMA K dimension (v_mfma_f32_16x16x4_f32: four tiles per instruction).  A persistent 512-thread block walks 2-row x 32-column pixel
+// tiles (16 Winograd tiles = 4 K steps); wave (a, nh) owns transform row a (positions (a, 0..3)) of the n half nh for all 64 k:
+// 4 x 2 x 4 accumulators of 4 registers = 128, alive across ALL tiles of the block.  The transformed operands never touch LDS: lane
+// (channel l15, tile g of the K step) forms its own A / B operand values from the raw pixels staged in LDS (double-buffered, one barrier
+// per tile): dY' from 2-4 raw values, V from 8, a few adds each -- 38 ds_read_b32 + 40 VALU per 32 MFMAs.  Epilogue: Gt dU G, the b
+// contraction in registers, the a contraction across the four waves of an n half through LDS -> ONE [9][64][64] partial slab per block,
+// summed by k_wgrad_reduce exactly as the direct kernel's.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int W2ROW = 72;                        // floats per staged pixel: two pixels = 144 = 16 banks mod 64 -> the four tiles of a K step read disjoint banks
+constexpr int W2XPIX = 4 * 34, W2GPIX = 2 * 32;
+constexpr int W2BUF = (W2XPIX + W2GPIX) * W2ROW;  // floats per buffer
+
+template <int TA>   // the wave's transform row a
+__device__ __forceinline__ void wgrad_wino_body(const Wgrad3Args& p, float* smw, f32x4 (&acc)[4][2][4], const int nh) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int ntiles = p.n_img * p.tiles_y * p.tiles_x;
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+  constexpr int WOOB = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+  float4 hx[5], hg[2];
+  auto load_tile = [&](int tile) {
+    int tx = tile % p.tiles_x; int qq = tile / p.tiles_x;
+    int ty = qq % p.tiles_y; int img = qq / p.tiles_y;
+    const int y0 = ty * 2, x0 = tx * 32;
+    const int ib = img * p.H * p.W;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + 512 * i, pix = idx >> 4, c16 = idx & 15;
+      const int r = pix / 34, c = pix - r * 34;
+      const int yy = y0 + r - 1, xx = x0 + c - 1;
+      const bool ok = pix < W2XPIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((ib + yy * p.W + xx) * p.x_stride + p.x_choff + c16 * 4) * 4 : WOOB, 0, 0));
+      hx[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, pix = idx >> 4, c16 = idx & 15;
+      const int r = pix >> 5, c = pix & 31;
+      const int yy = y0 + r, xx = x0 + c;
+      const bool ok = yy < p.H && xx < p.W;
+      const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? ((ib + yy * p.W + xx) * p.g_stride + p.g_choff + c16 * 4) * 4 : WOOB, 0, 0));
+      hg[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  int tile = blockIdx.x, it = 0;
+  if (tile < ntiles) load_tile(tile);
+  for (; tile < ntiles; tile += gridDim.x, ++it) {
+    float* const sX = smw + (it & 1) * W2BUF;
+    float* const sG = sX + W2XPIX * W2ROW;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + 512 * i, pix = idx >> 4, c16 = idx & 15;
+      if (pix < W2XPIX) *reinterpret_cast<float4*>(sX + pix * W2ROW + c16 * 4) = hx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, pix = idx >> 4, c16 = idx & 15;
+      *reinterpret_cast<float4*>(sG + pix * W2ROW + c16 * 4) = hg[i];
+    }
+    __syncthreads();   // (the only barrier of a tile: the other buffer was last read before the previous tile's barrier)
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);     // next tile flies under this tile's MFMAs
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      const int cx = 2 * (4 * s + g);           // first pixel column of this lane's Winograd tile (= its first halo column)
+      // A operands: dY'[a][b] of channels n = (2 nh + nb) 16 + l15
+      float av[2][4];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float* gp = sG + cx * W2ROW + (2 * nh + nb) * 16 + l15;
+        float r0, r1;
+        if (TA == 0) { r0 = gp[0]; r1 = gp[W2ROW]; }
+        else if (TA == 3) { r0 = -gp[32 * W2ROW]; r1 = -gp[33 * W2ROW]; }
+        else {
+          const float a0 = gp[0], a1 = gp[W2ROW], b0 = gp[32 * W2ROW], b1 = gp[33 * W2ROW];
+          r0 = TA == 1 ? a0 + b0 : a0 - b0; r1 = TA == 1 ? a1 + b1 : a1 - b1;
+        }
+        av[nb][0] = r0; av[nb][1] = r0 + r1; av[nb][2] = r0 - r1; av[nb][3] = -r1;
+      }
+      // B operands: V[a][b] of channels k = kb 16 + l15
+      float bv[4][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        constexpr int RA = TA == 0 ? 0 : TA == 3 ? 1 : 1, RB = TA == 0 ? 2 : TA == 3 ? 3 : 2;   // the two patch rows transform row a combines
+        const float* xa = sX + (RA * 34 + cx) * W2ROW + kb * 16 + l15;
+        const float* xb = sX + (RB * 34 + cx) * W2ROW + kb * 16 + l15;
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u = xa[j * W2ROW], v = xb[j * W2ROW];
+          t[j] = TA == 0 ? u - v : TA == 1 ? u + v : TA == 2 ? v - u : u - v;   // a = 0: d0 - d2; 1: d1 + d2; 2: d2 - d1; 3: d1 - d3
+        }
+        bv[kb][0] = t[0] - t[2]; bv[kb][1] = t[1] + t[2]; bv[kb][2] = t[2] - t[1]; bv[kb][3] = t[1] - t[3];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+            acc[b][nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nb][b], bv[kb][b], acc[b][nb][kb], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void k_wgrad_conv3_wino(Wgrad3Args p) {
+  extern __shared__ __attribute__((aligned(16))) float smw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int a = __builtin_amdgcn_readfirstlane(wave & 3), nh = __builtin_amdgcn_readfirstlane(wave >> 2);
+  f32x4 acc[4][2][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) acc[b][nb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a == 0) wgrad_wino_body<0>(p, smw, acc, nh);
+  else if (a == 1) wgrad_wino_body<1>(p, smw, acc, nh);
+  else if (a == 2) wgrad_wino_body<2>(p, smw, acc, nh);
+  else wgrad_wino_body<3>(p, smw, acc, nh);
+  // ---- dW = Gt dU G.  b contraction in registers: e[j] = sum_b G[b][j] dU[a][b]  (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1])
+  __syncthreads();                                   // the staging buffers are dead: reuse them for the exchange
+  float* out = p.P + (long long)blockIdx.x * 9 * 64 * 64;
+  float* ex = smw;                                   // [wave 8][8 blocks][4 regs][64 lanes] = 64 KB per round
+#pragma unroll 1
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const f32x4 u0 = acc[0][nb][kb], u1 = acc[1][nb][kb], u2 = acc[2][nb][kb], u3 = acc[3][nb][kb];
+        f32x4 e;
+        if (j == 0) e = u0 + 0.5f * (u1 + u2);
+        else if (j == 1) e = 0.5f * (u1 - u2);
+        else e = 0.5f * (u1 + u2) + u3;
+        *reinterpret_cast<f32x4*>(ex + (((wave * 8 + nb * 4 + kb) * 64 + lane) << 2)) = e;
+      }
+    __syncthreads();
+    // a contraction: dW[i][j] = sum_a G[a][i] e_a[j]; 3 x 2 n halves x 8 blocks x 256 values = 12288 float4-free scalars per round over 512 threads
+    for (int idx = tid; idx < 3 * 2 * 8 * 64; idx += 512) {
+      const int ln = idx & 63, blk = (idx >> 6) & 7, nh2 = (idx >> 9) & 1, i = idx >> 10;
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(ex + ((((nh2 * 4 + 0) * 8 + blk) * 64 + ln) << 2));
+      const f32x4 e1 = *reinterpret_cast<const f32x4*>(ex + ((((nh2 * 4 + 1) * 8 + blk) * 64 + ln) << 2));
+      const f32x4 e2 = *reinterpret_cast<const f32x4*>(ex + ((((nh2 * 4 + 2) * 8 + blk) * 64 + ln) << 2));
+      const f32x4 e3 = *reinterpret_cast<const f32x4*>(ex + ((((nh2 * 4 + 3) * 8 + blk) * 64 + ln) << 2));
+      f32x4 d;
+      if (i == 0) d = e0 + 0.5f * (e1 + e2);
+      else if (i == 1) d = 0.5f * (e1 - e2);
+      else d = 0.5f * (e1 + e2) + e3;
+      // D layout of the 16x16 block (nb, kb): lane ln holds column k = ln & 15, rows n = 4 (ln >> 4) + r
+      const int nb = blk >> 2, kb = blk & 3;
+      const int k = kb * 16 + (ln & 15), n0 = (2 * nh2 + nb) * 16 + 4 * (ln >> 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[((long long)(3 * i + j) * 64 + n0 + r) * 64 + k] = d[r];
+    }
+    __syncthreads();
+  }
+  (void)l15; (void)g;
+}
+
 // sum partial slabs in split order and scatter to the PyTorch layout (O, C, T): inverse of k_pack_weight.
 // P2 (optional) is a second partial set with the same geometry (the vertical EPI pass shares its weights).
 __global__ __launch_bounds__(512) void k_wgrad_reduce(const float* __restrict__ P, int nsplit, const float* __restrict__ P2, int nsplit2,
@@ -307,8 +474,12 @@ int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_
 }
 
 
+// LFSR_WGRAD3=direct keeps the direct-form kernel (A/B runs); the Winograd form is the default
+static bool wgrad3_wino() { const char* s = getenv("LFSR_WGRAD3"); return !(s && s[0] == 'd'); }
+
 int lfsr_wgrad_conv3_blocks(int n_img, int h, int w) {
-  long long tiles = (long long)n_img * ((h + WT_R - 1) / WT_R) * ((w + WT_C - 1) / WT_C);
+  const int tr = wgrad3_wino() ? 2 : WT_R;
+  long long tiles = (long long)n_img * ((h + tr - 1) / tr) * ((w + WT_C - 1) / WT_C);
   return (int)(tiles < 256 ? tiles : 256);
 }
 
@@ -320,10 +491,22 @@ int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const flo
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   const int smem = (WX_PIX + WG_PIX) * LDS_ROW * 4;
+  constexpr int smem_w = 2 * W2BUF * 4;
+  static_assert(smem_w >= 8 * 8 * 64 * 4 * 4, "the epilogue's exchange fits the staging buffers");
   if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_conv3_halo), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_conv3_wino), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
+  }
+  if (wgrad3_wino()) {
+    Wgrad3Args q{};
+    q.G = G; q.g_stride = g_stride; q.g_choff = g_choff; q.X = X; q.x_stride = x_stride; q.x_choff = x_choff; q.P = P;
+    q.g_bytes = (int)((long long)n_img * h * w * g_stride * 4); q.x_bytes = (int)((long long)n_img * h * w * x_stride * 4);
+    q.n_img = n_img; q.H = h; q.W = w; q.tiles_y = (h + 1) / 2; q.tiles_x = (w + WT_C - 1) / WT_C;
+    hipLaunchKernelGGL(k_wgrad_conv3_wino, dim3((unsigned)lfsr_wgrad_conv3_blocks(n_img, h, w)), dim3(512), smem_w, st, q);
+    LFSR_CHECK_LAUNCH();
+    return LFSR_OK;
   }
   Wgrad3Args p{};
   p.G = G; p.g_stride = g_stride; p.g_choff = g_choff; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P;

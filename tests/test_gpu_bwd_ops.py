@@ -1,5 +1,7 @@
 """GPU: the operator-level backward entry points of the C ABI (SURVEY 8b export list) through ctypes, against autograd over stock
 torch CPU ops of the same layer (what the reference's train.py:256-264 differentiates), and the RCCL all-reduce entry point."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -39,10 +41,16 @@ def test_conv3x3_dgrad_wgrad(n_img, h, w):
     dx2 = capi.conv3x3_dgrad(_vcl(dy), wT, n_img, h, w, res1=_vcl(skip), act=_vcl(act), act_slope=0.1)
     ref2 = dx_ref * torch.where(act > 0, 1.0, 0.1) + skip
     assert _rel(dx2.cpu(), _vcl_cpu(ref2)) <= 1e-4
-    dw = capi.conv3x3_wgrad(_vcl(dy), _vcl(xin.detach()), n_img, h, w)
-    assert _rel(dw.cpu(), dw_ref) <= 1e-4
-    dw2 = capi.conv3x3_wgrad(_vcl(dy), _vcl(xin.detach()), n_img, h, w, dw=dw.clone())      # accumulate
-    assert _rel(dw2.cpu(), 2 * dw_ref) <= 1e-4
+    for sel in ("", "direct"):          # the Winograd-domain (F(2x2,3x3) adjoint) kernel, default, and the direct-form one
+        if sel: os.environ["LFSR_WGRAD3"] = sel
+        else: os.environ.pop("LFSR_WGRAD3", None)
+        try:
+            dw = capi.conv3x3_wgrad(_vcl(dy), _vcl(xin.detach()), n_img, h, w)
+            assert _rel(dw.cpu(), dw_ref) <= 1e-4, sel
+            dw2 = capi.conv3x3_wgrad(_vcl(dy), _vcl(xin.detach()), n_img, h, w, dw=dw.clone())      # accumulate
+            assert _rel(dw2.cpu(), 2 * dw_ref) <= 1e-4, sel
+        finally:
+            os.environ.pop("LFSR_WGRAD3", None)
 
 
 def _vcl_cpu(t):
