@@ -220,6 +220,9 @@ __global__ __launch_bounds__(512) void k_wgrad_conv3_halo(Wgrad3Args p) {
 // contraction in registers, the a contraction across the four waves of an n half through LDS -> ONE [9][64][64] partial slab per block,
 // summed by k_wgrad_reduce exactly as the direct kernel's.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef W2_UNROLL
+#define W2_UNROLL 1     // K steps of a tile unrolled together (operand preparation of one step beside the MFMAs of another)
+#endif
 constexpr int W2ROW = 72;                        // floats per staged pixel: two pixels = 144 = 16 banks mod 64 -> the four tiles of a K step read disjoint banks
 constexpr int W2XPIX = 4 * 34, W2GPIX = 2 * 32;
 constexpr int W2BUF = (W2XPIX + W2GPIX) * W2ROW;  // floats per buffer
@@ -275,7 +278,7 @@ __device__ __forceinline__ void wgrad_wino_body(const Wgrad3Args& p, float* smw,
     }
     __syncthreads();   // (the only barrier of a tile: the other buffer was last read before the previous tile's barrier)
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);     // next tile flies under this tile's MFMAs
-#pragma unroll 1
+#pragma unroll W2_UNROLL
     for (int s = 0; s < 4; ++s) {
       const int cx = 2 * (4 * s + g);           // first pixel column of this lane's Winograd tile (= its first halo column)
       // A operands: dY'[a][b] of channels n = (2 nh + nb) 16 + l15
