@@ -303,6 +303,7 @@ size_t max_partial_floats(const lfsr_distgssr* c, int B, int h, int w) {
   auto up = [&](size_t v) { if (v > m) m = v; };
   up(lfsr_wgrad_partial_floats(npix, 9, 64, 64));
   up((size_t)256 * 9 * 64 * 64);
+  up((size_t)256 * AA * 32 * 64);   // EPI-line weight gradient: one slab per block
   up(lfsr_wgrad_partial_floats(npix, 1, 64, 144));
   up(lfsr_wgrad_partial_floats(nlr, AA, 16, 64));
   up(lfsr_wgrad_partial_floats(nlr, AA, 16, 16));
@@ -498,6 +499,7 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         RC(lfsr_bwd_gemm(q, st));
       }
       // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)
+      int epi_slabs[2] = {0, 0};
       for (int vert = 0; vert < 2; ++vert) {
         const float* E = vert ? t.EV[i] : t.EH[i];
         const int choff = vert ? 112 : 80;
@@ -509,7 +511,12 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         q.Wp = c->wT(p + "EPIConv.2.weight"); q.Y = t.dE32; q.y_stride = 32; q.Mk = E; q.mk_stride = 32; q.mk_slope = L;
         q.M = nepi; q.N = 32; q.A = A; q.h = h; q.w = w; q.ntaps = A; q.CH = 32;
         RC(lfsr_bwd_gemm(q, st));
-        RC(lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, t.dE32, 32, 0, Xin, 64, 0, Pb, nepi, 32, 64, A, h, w, AA, st));
+        {   // EPIConv.0 weight gradient: EPI-line kernel where it applies (one slab per block), else the gather form
+          int rc2 = lfsr_wgrad_epi0_launch(t.dE32, Xin, 64, 0, Pb, B, A, h, w, vert, st);
+          epi_slabs[vert] = rc2 == LFSR_OK ? lfsr_wgrad_epi0_blocks(B, A, h, w, vert) : lfsr_wgrad_splits(nepi, AA, 64);
+          if (rc2 == LFSR_E_ARG) rc2 = lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, t.dE32, 32, 0, Xin, 64, 0, Pb, nepi, 32, 64, A, h, w, AA, st);
+          RC(rc2);
+        }
         LfsrGemm r{};
         r.in_mode = vert ? LFSR_IN_LINE_V : LFSR_IN_LINE_H; r.out_mode = vert ? LFSR_OUT_EPIV : LFSR_OUT_EPIH; r.cin = 32; r.X = t.dE32; r.x_stride = 32;
         r.Wp = c->wT(p + "EPIConv.0.weight"); r.Y = gx; r.y_stride = 64; r.R1 = gx; r.r1_stride = 64;
@@ -517,7 +524,7 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         RC(lfsr_bwd_gemm(r, st));
       }
       RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nepi, A, 32), t.P[2], lfsr_wgrad_splits(nepi, A, 32), G(p + "EPIConv.2.weight"), 32 * A, 32, A, 0, 32, 0, 0, 1, st));
-      RC(lfsr_wgrad_reduce(t.P[1], lfsr_wgrad_splits(nepi, AA, 64), t.P[3], lfsr_wgrad_splits(nepi, AA, 64), G(p + "EPIConv.0.weight"), 32, 64, AA, 0, 0, 0, 0, 0, st));
+      RC(lfsr_wgrad_reduce(t.P[1], epi_slabs[0], t.P[3], epi_slabs[1], G(p + "EPIConv.0.weight"), 32, 64, AA, 0, 0, 0, 0, 0, st));
       gy = gx;
     }
     // group skip: grad at the group's input = (through the blocks) + dG

@@ -120,6 +120,8 @@ int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_
                       float* P, int M, int N, int K, int A, int h, int w, int ntaps, hipStream_t st);
 // halo-tile 3x3 conv weight gradient: partials P [lfsr_wgrad_conv3_blocks()][9][64][64], reduce with nsplit = that count
 int lfsr_wgrad_conv3_blocks(int n_img, int h, int w);
+int lfsr_wgrad_epi0_blocks(int B, int A, int h, int w, int vert);
+int lfsr_wgrad_epi0_launch(const float* dE, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st);
 int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P,
                             int n_img, int h, int w, hipStream_t st);
 // c_valid < C: only the first c_valid input channels are written, with row length c_valid (init_conv's 9 taps)

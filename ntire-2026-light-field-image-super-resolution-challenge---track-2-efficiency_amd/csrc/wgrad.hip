@@ -377,6 +377,98 @@ __global__ __launch_bounds__(512) void k_wgrad_conv3_wino(Wgrad3Args p) {
   (void)l15; (void)g;
 }
 
+// ---- EPIConv.0 weight gradient, EPI-line form ---------------------------------------------------------------------------------------
+// dW[tap = A dx + v'][n][c] = sum over the EPI lines (b, u, y) [vertical: (b, v, x)] and their pixels x of dE[line, x][n] * X[view v', x + dx - pad][c]
+// (DistgSSR.py:91-97: a 1 x A^2 conv, stride A, over the MacPI = a 5-tap 1-D conv along the line over A views x 64 channels).  The gather form
+// (k_wgrad<IN_SAME, IN_EPIH/V>) runs one block per tap and re-reads dE and the gathered rows for each of the A^2 taps.  Here a persistent
+// 512-thread block walks EPI lines (<= 32 pixels): the line's dE (32 x 32) and its A x 36 x 64 input slab (two pixels of zero halo) are
+// staged in LDS once (double-buffered, one barrier per line) and all A^2 taps read the slab at shifted addresses.  The PIXEL index is the MFMA K
+// dimension (v_mfma_f32_16x16x4_f32); wave (nh, cq) owns the 16 x 16 block (n half, channel quarter) of all 25 taps: 100 accumulator registers alive
+// across ALL lines of the block, one [A^2][32][64] partial slab per block at the end.  Pixel row strides 80 / 48 floats: the four pixels of a K
+// step read disjoint banks.
+constexpr int WE_SI = 80, WE_SE = 48, WE_PX = 36;
+
+struct WgradEpiArgs {
+  const float* G;            // dE rows ((q h + y) w + x), 32 channels
+  const float* X; int x_stride; int x_choff;
+  float* P;                  // [gridDim.x][A*A][32][64]
+  int g_bytes, x_bytes;
+  int B, A, H, W, vert;
+};
+
+template <int A>
+__global__ __launch_bounds__(512) void k_wgrad_epi0_lines(WgradEpiArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float sme[];
+  constexpr int BUF = A * WE_PX * WE_SI + 32 * WE_SE;   // floats per buffer
+  constexpr int NIN = (A * WE_PX * 16 + 511) / 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nh = wave >> 2, cq = wave & 3;
+  const int HW = p.H * p.W;
+  const int len = p.vert ? p.H : p.W, across = p.vert ? p.W : p.H;
+  const int nlines = p.B * A * across;
+  const int vstride = p.vert ? A * HW : HW, pstride = p.vert ? p.W : 1;
+  typedef float f32x4w __attribute__((ext_vector_type(4)));
+  constexpr int WOOB = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+  f32x4 acc[A * A];
+#pragma unroll
+  for (int t = 0; t < A * A; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 hin[NIN], he;
+  auto load_line = [&](int line) {
+    const int q = line / across, o = line - q * across;
+    int base, mbase;   // first pixel of the line in X (view 0); first dE row of the line
+    if (!p.vert) { base = q * A * HW + o * p.W; mbase = (q * p.H + o) * p.W; }
+    else { const int b = q / A, v = q - b * A; base = (b * A * A + v) * HW + o; mbase = q * HW + o; }
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = tid + 512 * i, c16 = idx & 15, pv = idx >> 4;
+      const int vv = pv / WE_PX, t = pv - vv * WE_PX - 2;
+      const bool ok = pv < A * WE_PX && t >= 0 && t < len;
+      const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? ((base + vv * vstride + t * pstride) * p.x_stride + p.x_choff + c16 * 4) * 4 : WOOB, 0, 0));
+      hin[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    {
+      const int px = tid >> 3, c8 = tid & 7;
+      const bool ok = tid < 256 && px < len;
+      const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? ((mbase + px * pstride) * 32 + c8 * 4) * 4 : WOOB, 0, 0));
+      he = make_float4(v.x, v.y, v.z, v.w);
+    }
+  };
+  int line = blockIdx.x, it = 0;
+  if (line < nlines) load_line(line);
+  for (; line < nlines; line += gridDim.x, ++it) {
+    float* const sIn = sme + (it & 1) * BUF;
+    float* const sE = sIn + A * WE_PX * WE_SI;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int idx = tid + 512 * i, c16 = idx & 15, pv = idx >> 4;
+      if (pv < A * WE_PX) *reinterpret_cast<float4*>(sIn + pv * WE_SI + c16 * 4) = hin[i];
+    }
+    if (tid < 256) *reinterpret_cast<float4*>(sE + (tid >> 3) * WE_SE + (tid & 7) * 4) = he;
+    __syncthreads();   // (the only barrier of a line: the other buffer was last read before the previous line's barrier)
+    if (line + (int)gridDim.x < nlines) load_line(line + gridDim.x);
+    const float* ep = sE + g * WE_SE + nh * 16 + l15;
+    const float* ip = sIn + g * WE_SI + cq * 16 + l15;
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+      const float a = ep[4 * s * WE_SE];
+#pragma unroll
+      for (int dx = 0; dx < A; ++dx)
+#pragma unroll
+        for (int vv = 0; vv < A; ++vv)
+          acc[dx * A + vv] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ip[(vv * WE_PX + 4 * s + dx) * WE_SI], acc[dx * A + vv], 0, 0, 0);
+    }
+  }
+  // D of block (nh, cq): lane holds column c = cq 16 + l15, rows n = nh 16 + 4 g + r
+  float* out = p.P + (long long)blockIdx.x * A * A * 32 * 64;
+#pragma unroll
+  for (int t = 0; t < A * A; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[((long long)t * 32 + nh * 16 + 4 * g + r) * 64 + cq * 16 + l15] = acc[t][r];
+}
+
 // sum partial slabs in split order and scatter to the PyTorch layout (O, C, T): inverse of k_pack_weight.
 // P2 (optional) is a second partial set with the same geometry (the vertical EPI pass shares its weights).
 __global__ __launch_bounds__(512) void k_wgrad_reduce(const float* __restrict__ P, int nsplit, const float* __restrict__ P2, int nsplit2,
@@ -545,5 +637,36 @@ int lfsr_pack_weight_T_m(const float* w, float* out, int O, int C, int T, int fl
   hipLaunchKernelGGL(k_pack_weight_T, dim3(grid), dim3(256), 0, st, w, out, O, C, T, npad32(C), flip);
   LFSR_CHECK_LAUNCH();
   if (O == 64 && C == 64 && T == 9 && flip == 1) return lfsr_pack_wino_m(out, out + LFSR_CONV3_DIRECT_FLOATS, mask, st);   // dgrad runs the Winograd kernel too
+  return LFSR_OK;
+}
+
+
+// EPIConv.0 weight gradient in EPI-line form (A = 5, lines of <= 32 pixels); LFSR_E_ARG = not covered (the caller keeps the gather form).
+// LFSR_WGRAD_EPI=gather forces the gather form (A/B runs).
+int lfsr_wgrad_epi0_blocks(int B, int A, int h, int w, int vert) {
+  const long long nl = (long long)B * A * (vert ? w : h);
+  return (int)(nl < 256 ? nl : 256);
+}
+
+int lfsr_wgrad_epi0_launch(const float* dE, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st) {
+  if (!dE || !X || !P || B <= 0 || h <= 0 || w <= 0 || ((x_stride | x_choff) & 3)) return LFSR_E_ARG;
+  const char* sel = getenv("LFSR_WGRAD_EPI");
+  if (A != 5 || (vert ? h : w) > 32 || (sel && sel[0] == 'g')) return LFSR_E_ARG;
+  if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  constexpr int smem = 2 * (5 * WE_PX * WE_SI + 32 * WE_SE) * 4;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_epi0_lines<5>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  WgradEpiArgs p{};
+  p.G = dE; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P;
+  p.g_bytes = (int)((long long)B * A * h * w * 32 * 4); p.x_bytes = (int)((long long)B * A * A * h * w * x_stride * 4);
+  p.B = B; p.A = A; p.H = h; p.W = w; p.vert = vert;
+  hipLaunchKernelGGL(k_wgrad_epi0_lines<5>, dim3((unsigned)lfsr_wgrad_epi0_blocks(B, A, h, w, vert)), dim3(512), smem, st, p);
+  LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
