@@ -141,6 +141,152 @@ __global__ __launch_bounds__(256) void k_add_inplace(float4* __restrict__ a, con
 
 }  // namespace
 
+// ---- EPIConv.0 data gradient, EPI-line form -------------------------------------------------------------------------------------------
+// dX[line, view v', x'][c] += sum_{dx, n} dE[line, x' + pad - dx][n] * W[tap = A dx + v'][n][c]   (the adjoint of the 1 x A^2, stride-A conv of
+// DistgSSR.py:91-97 along an EPI line).  The gather form (k_gemm_gather<IN_LINE_*, OUT_EPI*>) re-gathers dE rows per tap and scatters 64-channel
+// rows per view.  Here a persistent 512-thread block takes chunks of 5 EPI lines (<= 32 pixels each): the lines' dE (36 x 32 with two pixels of
+// zero halo) are staged in LDS once per chunk, then one phase per destination view v': its 5 x 32 x 64 weights are staged (double-buffered) and
+// wave (pb, cb) computes D[c 16][x' 16] of every line with v_mfma_f32_16x16x4_f32 (A = W^t, B = dE, K = n): a lane holds four consecutive CHANNELS
+// of one pixel, so the accumulate-into-dX epilogue is one 16-B load + one 16-B store per line.  Both operands sit in LDS with the K index permuted
+// (n = 4 s + g stored at 8 g + s), so a lane reads the eight K steps of a (tap, line) pair with two ds_read_b128.
+constexpr int ED_WR = 36, ED_L = 5;
+
+struct EpiDgradArgs {
+  const float* G;            // dE rows ((q h + y) w + x), 32 channels
+  const float* Wd;           // direct pack [A*A taps][32][64]
+  float* Y; int y_stride; int y_choff;     // dX (read-modify-write)
+  int g_bytes, y_bytes;
+  int B, A, H, W, vert;
+};
+
+template <int A>
+__global__ __launch_bounds__(512) void k_epi0_dgrad_lines(EpiDgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smd[];
+  constexpr int WBUF = A * 64 * ED_WR;            // floats per weight buffer
+  float* const sE = smd + 2 * WBUF;               // [ED_L][36][ED_WR]
+  typedef float f32x4d __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int pb = wave >> 2, cb = wave & 3;
+  const int HW = p.H * p.W;
+  const int len = p.vert ? p.H : p.W, across = p.vert ? p.W : p.H;
+  const int nlines = p.B * A * across;
+  const int vstride = p.vert ? A * HW : HW, pstride = p.vert ? p.W : 1;
+  constexpr int DOOB = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, p.y_bytes, 0x00020000);
+  const int nchunks = (nlines + ED_L - 1) / ED_L;
+  float4 wr[A];
+  auto load_w = [&](int vv) {
+#pragma unroll
+    for (int i = 0; i < A; ++i) {   // idx = tid + 512 i over (dx, n, c4): dx = i, n = tid >> 4, c4 = tid & 15
+      wr[i] = *reinterpret_cast<const float4*>(p.Wd + ((long long)(i * A + vv) * 32 + (tid >> 4)) * 64 + (tid & 15) * 4);
+    }
+  };
+  auto store_w = [&](float* buf) {
+    const int n = tid >> 4, c0 = (tid & 15) * 4, kperm = (n & 3) * 8 + (n >> 2);
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+      float* d = buf + (i * 64 + c0) * ED_WR + kperm;
+      d[0] = wr[i].x; d[ED_WR] = wr[i].y; d[2 * ED_WR] = wr[i].z; d[3 * ED_WR] = wr[i].w;
+    }
+  };
+  for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const int line0 = chunk * ED_L;
+    __syncthreads();                               // the previous chunk's phases are done with sE and the weight buffers
+    // ---- the chunk's dE lines -> sE (halo pixels and missing lines zero), K index permuted
+    for (int idx = tid; idx < ED_L * 36 * 8; idx += 512) {
+      const int n4 = idx & 7, px = (idx >> 3) % 36, ln = idx / (36 * 8);
+      const int line = line0 + ln, t = px - 2;
+      int off = DOOB;
+      if (line < nlines && t >= 0 && t < len) {
+        const int q = line / across, o = line - q * across;
+        const int mbase = p.vert ? q * HW + o : (q * p.H + o) * p.W;
+        off = ((mbase + t * pstride) * 32 + n4 * 4) * 4;
+      }
+      const f32x4d v = __builtin_bit_cast(f32x4d, __builtin_amdgcn_raw_buffer_load_b128(rsG, off, 0, 0));
+      float* d = sE + (ln * 36 + px) * ED_WR + n4;   // n = 4 n4 + k -> (n & 3) * 8 + (n >> 2) = 8 k + n4
+      d[0] = v.x; d[8] = v.y; d[16] = v.z; d[24] = v.w;
+    }
+    load_w(0);
+    store_w(smd);
+    // this lane's pixel of each line of the chunk (x' = pb 16 + l15) in dX: byte offset of its 4 channels, or out of range
+    int yoff[ED_L];
+#pragma unroll
+    for (int ln = 0; ln < ED_L; ++ln) {
+      const int line = line0 + ln, xq = pb * 16 + l15;
+      yoff[ln] = DOOB;
+      if (line < nlines && xq < len) {
+        const int q = line / across, o = line - q * across;
+        int base;
+        if (!p.vert) base = q * A * HW + o * p.W;
+        else { const int b = q / A, v = q - b * A; base = (b * A * A + v) * HW + o; }
+        yoff[ln] = ((base + xq * pstride) * p.y_stride + p.y_choff + cb * 16 + 4 * g) * 4;
+      }
+    }
+#pragma unroll 1
+    for (int vv = 0; vv < A; ++vv) {
+      __syncthreads();                             // weights of view vv (and, for vv = 0, the dE lines) are staged; the other buffer is free
+      if (vv + 1 < A) load_w(vv + 1);
+      const float* sW = smd + (vv & 1) * WBUF;
+      const int vbytes = vv * vstride * p.y_stride * 4;   // wave-uniform
+      f32x4d old[ED_L];
+#pragma unroll
+      for (int ln = 0; ln < ED_L; ++ln) old[ln] = __builtin_bit_cast(f32x4d, __builtin_amdgcn_raw_buffer_load_b128(rsY, yoff[ln], vbytes, 0));
+      f32x4d acc[ED_L];
+#pragma unroll
+      for (int ln = 0; ln < ED_L; ++ln) acc[ln] = f32x4d{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dx = 0; dx < A; ++dx) {
+        const float* ap = sW + (dx * 64 + cb * 16 + l15) * ED_WR + 8 * g;
+        const f32x4d a0 = *reinterpret_cast<const f32x4d*>(ap), a1 = *reinterpret_cast<const f32x4d*>(ap + 4);
+#pragma unroll
+        for (int ln = 0; ln < ED_L; ++ln) {
+          const float* bp = sE + (ln * 36 + pb * 16 + l15 + 4 - dx) * ED_WR + 8 * g;
+          const f32x4d b0 = *reinterpret_cast<const f32x4d*>(bp), b1 = *reinterpret_cast<const f32x4d*>(bp + 4);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[ln], 0, 0, 0);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[ln], 0, 0, 0);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[ln], 0, 0, 0);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[ln], 0, 0, 0);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[ln], 0, 0, 0);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[ln], 0, 0, 0);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[ln], 0, 0, 0);
+          acc[ln] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[ln], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ln = 0; ln < ED_L; ++ln)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned int, old[ln] + acc[ln]), rsY, yoff[ln], vbytes, 0);
+      if (vv + 1 < A) store_w(smd + ((vv + 1) & 1) * WBUF);   // (the other buffer: last read in phase vv - 1, which every wave left before this phase's barrier)
+    }
+  }
+}
+
+// LFSR_E_ARG = not covered (the caller keeps the gather-GEMM).  LFSR_DGRAD_EPI=gather forces the gather form (A/B runs).
+int lfsr_epi0_dgrad_launch(const float* dE, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, int vert, hipStream_t st) {
+  if (!dE || !w_direct || !dx || B <= 0 || h <= 0 || w <= 0 || ((dx_stride | dx_choff) & 3)) return LFSR_E_ARG;
+  const char* sel = getenv("LFSR_DGRAD_EPI");
+  if (A != 5 || (vert ? h : w) > 32 || (sel && sel[0] == 'g')) return LFSR_E_ARG;
+  if ((long long)B * A * A * h * w * dx_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  constexpr int smem = (2 * 5 * 64 * ED_WR + ED_L * 36 * ED_WR) * 4;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi0_dgrad_lines<5>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  EpiDgradArgs p{};
+  p.G = dE; p.Wd = w_direct; p.Y = dx; p.y_stride = dx_stride; p.y_choff = dx_choff;
+  p.g_bytes = (int)((long long)B * A * h * w * 32 * 4); p.y_bytes = (int)((long long)B * A * A * h * w * dx_stride * 4);
+  p.B = B; p.A = A; p.H = h; p.W = w; p.vert = vert;
+  const long long nchunks = ((long long)B * A * (vert ? w : h) + ED_L - 1) / ED_L;
+  hipLaunchKernelGGL(k_epi0_dgrad_lines<5>, dim3((unsigned)(nchunks < 256 ? nchunks : 256)), dim3(512), smem, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
 int lfsr_add_inplace(float* a, const float* b, long long n, hipStream_t st) {
   if (n & 3) return LFSR_E_ARG;
   unsigned grid = lfsr_blocks(n / 4, 256);

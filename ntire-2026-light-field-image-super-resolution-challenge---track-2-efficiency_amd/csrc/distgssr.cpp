@@ -521,7 +521,11 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         r.in_mode = vert ? LFSR_IN_LINE_V : LFSR_IN_LINE_H; r.out_mode = vert ? LFSR_OUT_EPIV : LFSR_OUT_EPIH; r.cin = 32; r.X = t.dE32; r.x_stride = 32;
         r.Wp = c->wT(p + "EPIConv.0.weight"); r.Y = gx; r.y_stride = 64; r.R1 = gx; r.r1_stride = 64;
         r.M = nepi; r.N = A * 64; r.A = A; r.h = h; r.w = w; r.ntaps = A; r.CH = 64;
-        RC(lfsr_bwd_gemm(r, st));
+        {   // EPIConv.0 data gradient (accumulates into gx): EPI-line kernel where it applies, else the gather-GEMM
+          int rc3 = lfsr_epi0_dgrad_launch(t.dE32, c->w(p + "EPIConv.0.weight"), gx, 64, 0, B, A, h, w, vert, st);
+          if (rc3 == LFSR_E_ARG) rc3 = lfsr_bwd_gemm(r, st);
+          RC(rc3);
+        }
       }
       RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nepi, A, 32), t.P[2], lfsr_wgrad_splits(nepi, A, 32), G(p + "EPIConv.2.weight"), 32 * A, 32, A, 0, 32, 0, 0, 1, st));
       RC(lfsr_wgrad_reduce(t.P[1], epi_slabs[0], t.P[3], epi_slabs[1], G(p + "EPIConv.0.weight"), 32, 64, AA, 0, 0, 0, 0, 0, st));
