@@ -287,6 +287,51 @@ int lfsr_epi0_dgrad_launch(const float* dE, const float* w_direct, float* dx, in
   return LFSR_OK;
 }
 
+// ---- AngConv.0 data gradient, streaming form -------------------------------------------------------------------------------------------------
+// dX[b, view, y, x][c] += sum_n dA[b, y, x][n] * W[view][n][c]   (the adjoint of the A x A, stride-A conv over the MacPI: DistgSSR.py:84-90).  K is only 16, so this
+// is a read-modify-write stream over dX (25 views x 64 channels per LR pixel) with 16 FMAs per element: plain VALU, 16 B per lane, the view's 16 x 64 weights in LDS,
+// the pixel's 16 gradient values from L1 -- no MFMA, no gather-GEMM.  Block = one (b, view) image, 16 pixels x 16 channel quads per pass.
+__global__ __launch_bounds__(256) void k_ang0_dgrad(const float* __restrict__ dA, const float* __restrict__ Wd, float* __restrict__ dX, int dx_stride, int dx_choff,
+                                                    int AA, int HW, int chunks) {
+  __shared__ __attribute__((aligned(16))) float sWv[16 * 64];
+  const int tid = threadIdx.x, c4 = tid & 15, pr = tid >> 4;
+  const int img = blockIdx.x / chunks, chunk = blockIdx.x - img * chunks;   // img = b * AA + view
+  const int b = img / AA, view = img - b * AA;
+  // direct pack [tap = view][Npad = 32][64]: rows n < 16
+  for (int i = tid; i < 16 * 16; i += 256) *reinterpret_cast<float4*>(sWv + i * 4) = *reinterpret_cast<const float4*>(Wd + ((long long)view * 32 + (i >> 4)) * 64 + (i & 15) * 4);
+  __syncthreads();
+  const int per = (HW + chunks - 1) / chunks;
+  const int p0 = chunk * per, p1 = p0 + per < HW ? p0 + per : HW;
+  for (int px = p0 + pr; px < p1; px += 16) {
+    const float4* ga = reinterpret_cast<const float4*>(dA + ((long long)b * HW + px) * 16);
+    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2], g3 = ga[3];
+    float4* dst = reinterpret_cast<float4*>(dX + ((long long)img * HW + px) * dx_stride + dx_choff + c4 * 4);
+    float4 acc = *dst;
+    const float gv[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      const float4 wv = *reinterpret_cast<const float4*>(sWv + n * 64 + c4 * 4);
+      acc.x = fmaf(gv[n], wv.x, acc.x); acc.y = fmaf(gv[n], wv.y, acc.y); acc.z = fmaf(gv[n], wv.z, acc.z); acc.w = fmaf(gv[n], wv.w, acc.w);
+    }
+    *dst = acc;
+  }
+}
+
+// LFSR_DGRAD_ANG=gather keeps the gather-GEMM (A/B runs); LFSR_E_ARG = not covered
+int lfsr_ang0_dgrad_launch(const float* dA16, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, hipStream_t st) {
+  if (!dA16 || !w_direct || !dx || B <= 0 || A <= 0 || h <= 0 || w <= 0 || ((dx_stride | dx_choff) & 3)) return LFSR_E_ARG;
+  const char* sel = getenv("LFSR_DGRAD_ANG");
+  if (sel && sel[0] == 'g') return LFSR_E_ARG;
+  const int AA = A * A, HW = h * w;
+  int chunks = (HW + 255) / 256;            // >= 256 pixels per block
+  if (chunks < 1) chunks = 1;
+  const long long nblk = (long long)B * AA * chunks;
+  if (nblk > 0x7fffffffLL) return LFSR_E_ARG;
+  hipLaunchKernelGGL(k_ang0_dgrad, dim3((unsigned)nblk), dim3(256), 0, st, dA16, w_direct, dx, dx_stride, dx_choff, AA, HW, chunks);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
 int lfsr_add_inplace(float* a, const float* b, long long n, hipStream_t st) {
   if (n & 3) return LFSR_E_ARG;
   unsigned grid = lfsr_blocks(n / 4, 256);

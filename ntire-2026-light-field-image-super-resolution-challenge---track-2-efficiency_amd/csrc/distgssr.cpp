@@ -496,7 +496,9 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         q.in_mode = LFSR_IN_SAME; q.out_mode = LFSR_OUT_VIEWS; q.cin = 16; q.X = t.dA16; q.x_stride = 16; q.Wp = c->wT(p + "AngConv.0.weight");
         q.Y = gx; q.y_stride = 64; q.R1 = gx; q.r1_stride = 64;
         q.M = nlr; q.N = AA * 64; q.A = A; q.h = h; q.w = w; q.ntaps = 1; q.CH = 64;
-        RC(lfsr_bwd_gemm(q, st));
+        int rc4 = lfsr_ang0_dgrad_launch(t.dA16, c->w(p + "AngConv.0.weight"), gx, 64, 0, B, A, h, w, st);   // streaming read-modify-write form; else the gather-GEMM
+        if (rc4 == LFSR_E_ARG) rc4 = lfsr_bwd_gemm(q, st);
+        RC(rc4);
       }
       // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)
       int epi_slabs[2] = {0, 0};

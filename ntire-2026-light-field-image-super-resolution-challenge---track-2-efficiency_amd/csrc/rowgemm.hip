@@ -93,6 +93,18 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
     }
     __syncthreads();
     if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    // (backward) the LeakyReLU' mask operand of THIS tile's epilogue is requested here, so its HBM latency runs under the MFMAs
+    float4 mkv[NT][4];
+    if (p.Mk) {
+      const long long mm = tile * BMR + rg * 32 + l31;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + ng * (NB / 2) + t * 32 + 4 * half + 8 * q;
+          mkv[t][q] = (mm < p.M && n + 3 < p.N) ? *reinterpret_cast<const float4*>(p.Mk + mm * p.mk_stride + p.mk_choff + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+    }
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
             for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
             if (p.R1) { v[0] += rv[q].x; v[1] += rv[q].y; v[2] += rv[q].z; v[3] += rv[q].w; }
             if (p.Mk) {
-              const float4 mk = *reinterpret_cast<const float4*>(p.Mk + m * p.mk_stride + p.mk_choff + n);
+              const float4 mk = mkv[t][q];
               v[0] *= mk.x > 0.f ? 1.f : p.mk_slope; v[1] *= mk.y > 0.f ? 1.f : p.mk_slope; v[2] *= mk.z > 0.f ? 1.f : p.mk_slope; v[3] *= mk.w > 0.f ? 1.f : p.mk_slope;
             }
             *reinterpret_cast<float4*>(p.Y + m * p.y_stride + p.y_choff + n) = make_float4(v[0], v[1], v[2], v[3]);
