@@ -291,7 +291,7 @@ struct TrainWs {
   float *F0, *D;
   std::vector<float*> S1, CAT, A16, EH, EV, FZ, OUT, GOUT;
   // backward scratch
-  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *G16, *XG9, *P[4], *small;
+  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *dE32V, *G16, *XG9, *P[4], *small;
   size_t pfloats;
   size_t total;
 };
@@ -328,7 +328,7 @@ void train_layout(const lfsr_distgssr* c, int B, int h, int w, float* base, Trai
   for (int g = 0; g < c->G; ++g) t.GOUT[g] = take(npix * 64);
   for (int i = 0; i < 4; ++i) t.g[i] = take(npix * 64);
   t.dF = take(npix * 64); t.dS1 = take(npix * 64); t.dCAT = take(npix * 144);
-  t.dA16 = take(nlr * 16); t.dE32 = take(nepi * 32); t.G16 = take(npix * 16); t.XG9 = take(npix * 16);
+  t.dA16 = take(nlr * 16); t.dE32 = take(nepi * 32); t.dE32V = take(nepi * 32); t.G16 = take(npix * 16); t.XG9 = take(npix * 16);
   t.pfloats = max_partial_floats(c, B, h, w);
   for (int i = 0; i < 4; ++i) t.P[i] = take(t.pfloats);
   t.small = take(64 * 1024);
@@ -501,36 +501,42 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         RC(rc4);
       }
       // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)
+      // the two passes share EPIConv.0's weights: where the EPI-line kernel applies, ONE weight-gradient launch covers both (one slab per block
+      // instead of two sets), after both passes' dE exist; else the gather form per pass
+      const bool epi_merged = lfsr_wgrad_epi0_blocks(B, A, h, w, 2) > 0 && A == 5 && h <= 32 && w <= 32 && (long long)npix * 64 * 4 < (1LL << 31) && !(getenv("LFSR_WGRAD_EPI") && getenv("LFSR_WGRAD_EPI")[0] == 'g');
       int epi_slabs[2] = {0, 0};
       for (int vert = 0; vert < 2; ++vert) {
         const float* E = vert ? t.EV[i] : t.EH[i];
+        float* dE = vert ? t.dE32V : t.dE32;
         const int choff = vert ? 112 : 80;
         float* Pa = t.P[vert ? 2 : 0];   // EPIConv.2 partials
         float* Pb = t.P[vert ? 3 : 1];   // EPIConv.0 partials
         RC(lfsr_wgrad_launch(vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H, LFSR_IN_SAME, t.dCAT, 144, choff, E, 32, 0, Pa, nepi, 32, 32, A, h, w, A, st));
         LfsrGemm q{};
         q.in_mode = vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H; q.out_mode = LFSR_OUT_SAME; q.cin = 32; q.X = t.dCAT; q.x_stride = 144; q.x_choff = choff;
-        q.Wp = c->wT(p + "EPIConv.2.weight"); q.Y = t.dE32; q.y_stride = 32; q.Mk = E; q.mk_stride = 32; q.mk_slope = L;
+        q.Wp = c->wT(p + "EPIConv.2.weight"); q.Y = dE; q.y_stride = 32; q.Mk = E; q.mk_stride = 32; q.mk_slope = L;
         q.M = nepi; q.N = 32; q.A = A; q.h = h; q.w = w; q.ntaps = A; q.CH = 32;
         RC(lfsr_bwd_gemm(q, st));
-        {   // EPIConv.0 weight gradient: EPI-line kernel where it applies (one slab per block), else the gather form
-          int rc2 = lfsr_wgrad_epi0_launch(t.dE32, Xin, 64, 0, Pb, B, A, h, w, vert, st);
-          epi_slabs[vert] = rc2 == LFSR_OK ? lfsr_wgrad_epi0_blocks(B, A, h, w, vert) : lfsr_wgrad_splits(nepi, AA, 64);
-          if (rc2 == LFSR_E_ARG) rc2 = lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, t.dE32, 32, 0, Xin, 64, 0, Pb, nepi, 32, 64, A, h, w, AA, st);
-          RC(rc2);
+        if (!epi_merged) {
+          RC(lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, dE, 32, 0, Xin, 64, 0, Pb, nepi, 32, 64, A, h, w, AA, st));
+          epi_slabs[vert] = lfsr_wgrad_splits(nepi, AA, 64);
         }
         LfsrGemm r{};
-        r.in_mode = vert ? LFSR_IN_LINE_V : LFSR_IN_LINE_H; r.out_mode = vert ? LFSR_OUT_EPIV : LFSR_OUT_EPIH; r.cin = 32; r.X = t.dE32; r.x_stride = 32;
+        r.in_mode = vert ? LFSR_IN_LINE_V : LFSR_IN_LINE_H; r.out_mode = vert ? LFSR_OUT_EPIV : LFSR_OUT_EPIH; r.cin = 32; r.X = dE; r.x_stride = 32;
         r.Wp = c->wT(p + "EPIConv.0.weight"); r.Y = gx; r.y_stride = 64; r.R1 = gx; r.r1_stride = 64;
         r.M = nepi; r.N = A * 64; r.A = A; r.h = h; r.w = w; r.ntaps = A; r.CH = 64;
         {   // EPIConv.0 data gradient (accumulates into gx): EPI-line kernel where it applies, else the gather-GEMM
-          int rc3 = lfsr_epi0_dgrad_launch(t.dE32, c->w(p + "EPIConv.0.weight"), gx, 64, 0, B, A, h, w, vert, st);
+          int rc3 = lfsr_epi0_dgrad_launch(dE, c->w(p + "EPIConv.0.weight"), gx, 64, 0, B, A, h, w, vert, st);
           if (rc3 == LFSR_E_ARG) rc3 = lfsr_bwd_gemm(r, st);
           RC(rc3);
         }
       }
+      if (epi_merged) {
+        RC(lfsr_wgrad_epi0_launch(t.dE32, t.dE32V, Xin, 64, 0, t.P[1], B, A, h, w, 2, st));
+        epi_slabs[0] = lfsr_wgrad_epi0_blocks(B, A, h, w, 2);
+      }
       RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nepi, A, 32), t.P[2], lfsr_wgrad_splits(nepi, A, 32), G(p + "EPIConv.2.weight"), 32 * A, 32, A, 0, 32, 0, 0, 1, st));
-      RC(lfsr_wgrad_reduce(t.P[1], epi_slabs[0], t.P[3], epi_slabs[1], G(p + "EPIConv.0.weight"), 32, 64, AA, 0, 0, 0, 0, 0, st));
+      RC(lfsr_wgrad_reduce(t.P[1], epi_slabs[0], epi_slabs[1] ? t.P[3] : nullptr, epi_slabs[1], G(p + "EPIConv.0.weight"), 32, 64, AA, 0, 0, 0, 0, 0, st));
       gy = gx;
     }
     // group skip: grad at the group's input = (through the blocks) + dG

@@ -123,7 +123,7 @@ int lfsr_wgrad_conv3_blocks(int n_img, int h, int w);
 int lfsr_wgrad_epi0_blocks(int B, int A, int h, int w, int vert);
 int lfsr_ang0_dgrad_launch(const float* dA16, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, hipStream_t st);
 int lfsr_epi0_dgrad_launch(const float* dE, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, int vert, hipStream_t st);
-int lfsr_wgrad_epi0_launch(const float* dE, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st);
+int lfsr_wgrad_epi0_launch(const float* dE, const float* dE_v, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st);
 int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P,
                             int n_img, int h, int w, hipStream_t st);
 // c_valid < C: only the first c_valid input channels are written, with row length c_valid (init_conv's 9 taps)

@@ -389,6 +389,7 @@ __global__ __launch_bounds__(512) void k_wgrad_conv3_wino(Wgrad3Args p) {
 constexpr int WE_SI = 80, WE_SE = 48, WE_PX = 36;
 
 struct WgradEpiArgs {
+  const float* G2;           // (vert == 2: both passes in one launch) the vertical pass's dE; lines [0, nH) are horizontal (G), the rest vertical (G2)
   const float* G;            // dE rows ((q h + y) w + x), 32 channels
   const float* X; int x_stride; int x_choff;
   float* P;                  // [gridDim.x][A*A][32][64]
@@ -405,21 +406,25 @@ __global__ __launch_bounds__(512) void k_wgrad_epi0_lines(WgradEpiArgs p) {
   const int l15 = lane & 15, g = lane >> 4;
   const int nh = wave >> 2, cq = wave & 3;
   const int HW = p.H * p.W;
-  const int len = p.vert ? p.H : p.W, across = p.vert ? p.W : p.H;
-  const int nlines = p.B * A * across;
-  const int vstride = p.vert ? A * HW : HW, pstride = p.vert ? p.W : 1;
+  const int nH = p.vert == 1 ? 0 : p.B * A * p.H, nV = p.vert == 0 ? 0 : p.B * A * p.W;   // horizontal lines (b, u, y), vertical lines (b, v, x)
+  const int nlines = nH + nV;
   typedef float f32x4w __attribute__((ext_vector_type(4)));
   constexpr int WOOB = (int)0x80000000u;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsG2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.vert == 2 ? p.G2 : p.G), 0, p.g_bytes, 0x00020000);
   f32x4 acc[A * A];
 #pragma unroll
   for (int t = 0; t < A * A; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float4 hin[NIN], he;
   auto load_line = [&](int line) {
-    const int q = line / across, o = line - q * across;
+    const bool vert = line >= nH;                     // wave-uniform
+    const int ln = vert ? line - nH : line;
+    const int len = vert ? p.H : p.W, across = vert ? p.W : p.H;
+    const int vstride = vert ? A * HW : HW, pstride = vert ? p.W : 1;
+    const int q = ln / across, o = ln - q * across;
     int base, mbase;   // first pixel of the line in X (view 0); first dE row of the line
-    if (!p.vert) { base = q * A * HW + o * p.W; mbase = (q * p.H + o) * p.W; }
+    if (!vert) { base = q * A * HW + o * p.W; mbase = (q * p.H + o) * p.W; }
     else { const int b = q / A, v = q - b * A; base = (b * A * A + v) * HW + o; mbase = q * HW + o; }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
@@ -432,7 +437,9 @@ __global__ __launch_bounds__(512) void k_wgrad_epi0_lines(WgradEpiArgs p) {
     {
       const int px = tid >> 3, c8 = tid & 7;
       const bool ok = tid < 256 && px < len;
-      const f32x4w v = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsG, ok ? ((mbase + px * pstride) * 32 + c8 * 4) * 4 : WOOB, 0, 0));
+      const int off = ok ? ((mbase + px * pstride) * 32 + c8 * 4) * 4 : WOOB;
+      const f32x4w v = vert ? __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsG2, off, 0, 0))
+                            : __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsG, off, 0, 0));
       he = make_float4(v.x, v.y, v.z, v.w);
     }
   };
@@ -643,15 +650,16 @@ int lfsr_pack_weight_T_m(const float* w, float* out, int O, int C, int T, int fl
 
 // EPIConv.0 weight gradient in EPI-line form (A = 5, lines of <= 32 pixels); LFSR_E_ARG = not covered (the caller keeps the gather form).
 // LFSR_WGRAD_EPI=gather forces the gather form (A/B runs).
+// vert: 0 horizontal pass (dE), 1 vertical pass (dE), 2 both in one launch (dE = horizontal, dE_v = vertical): one slab set for the shared weights
 int lfsr_wgrad_epi0_blocks(int B, int A, int h, int w, int vert) {
-  const long long nl = (long long)B * A * (vert ? w : h);
+  const long long nl = (long long)B * A * (vert == 2 ? h + w : vert ? w : h);
   return (int)(nl < 256 ? nl : 256);
 }
 
-int lfsr_wgrad_epi0_launch(const float* dE, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st) {
-  if (!dE || !X || !P || B <= 0 || h <= 0 || w <= 0 || ((x_stride | x_choff) & 3)) return LFSR_E_ARG;
+int lfsr_wgrad_epi0_launch(const float* dE, const float* dE_v, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st) {
+  if (!dE || !X || !P || B <= 0 || h <= 0 || w <= 0 || ((x_stride | x_choff) & 3) || vert < 0 || vert > 2 || (vert == 2 && !dE_v)) return LFSR_E_ARG;
   const char* sel = getenv("LFSR_WGRAD_EPI");
-  if (A != 5 || (vert ? h : w) > 32 || (sel && sel[0] == 'g')) return LFSR_E_ARG;
+  if (A != 5 || (vert != 0 && h > 32) || (vert != 1 && w > 32) || (sel && sel[0] == 'g')) return LFSR_E_ARG;
   if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
@@ -663,7 +671,7 @@ int lfsr_wgrad_epi0_launch(const float* dE, const float* X, int x_stride, int x_
     attr_set[dev] = true;
   }
   WgradEpiArgs p{};
-  p.G = dE; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P;
+  p.G = dE; p.G2 = dE_v; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P;
   p.g_bytes = (int)((long long)B * A * h * w * 32 * 4); p.x_bytes = (int)((long long)B * A * A * h * w * x_stride * 4);
   p.B = B; p.A = A; p.H = h; p.W = w; p.vert = vert;
   hipLaunchKernelGGL(k_wgrad_epi0_lines<5>, dim3((unsigned)lfsr_wgrad_epi0_blocks(B, A, h, w, vert)), dim3(512), smem, st, p);

@@ -328,3 +328,33 @@ def test_graph_replayed_repack_equals_eager(monkeypatch):
     assert runs[0][0] == runs[1][0]
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
     assert runs[0][0][-1] < runs[0][0][0]      # and it trains
+
+
+def test_line_form_gradient_kernels_equal_the_gather_forms(monkeypatch):
+    """the round-2 backward kernels (Winograd-form 3x3 weight gradient, EPI-line weight / data gradients of EPIConv.0, streaming AngConv.0 data gradient,
+    row-GEMM fuse.0 data gradient) against the direct / gather-GEMM forms they replaced, selected by environment variables: the same gradients to fp32
+    round-off for every parameter (angRes 5, the ragged-free reduced geometry and a batch of 2)"""
+    case, sd, x, _ = model_case("DistgSSR", "a5h8s4")
+    A, s = 5, 4
+    M = load_plugin()
+    xb = torch.from_numpy(np.concatenate([x, 0.5 * x[:, :, ::-1].copy()], 0)).cuda()
+    label = torch.from_numpy(synth_input((2, 1, xb.shape[2] * s, xb.shape[3] * s), seed=4)).cuda()
+    def grads(env):
+        for k in ("LFSR_WGRAD3", "LFSR_WGRAD_EPI", "LFSR_DGRAD_EPI", "LFSR_DGRAD_ANG", "LFSR_NO_ROWGEMM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = build(M, A, s, sd)
+        torch.nn.functional.l1_loss(net(xb, None), label).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().double().cpu() for k, p in net.named_parameters()}
+    new = grads({})
+    old = grads({"LFSR_WGRAD3": "direct", "LFSR_WGRAD_EPI": "gather", "LFSR_DGRAD_EPI": "gather", "LFSR_DGRAD_ANG": "gather", "LFSR_NO_ROWGEMM": "1"})
+    for k in ("LFSR_WGRAD3", "LFSR_WGRAD_EPI", "LFSR_DGRAD_EPI", "LFSR_DGRAD_ANG", "LFSR_NO_ROWGEMM"):
+        monkeypatch.delenv(k, raising=False)
+    worst = 0.0
+    for k in new:
+        rel = float((new[k] - old[k]).norm() / old[k].norm().clamp_min(1e-30))
+        worst = max(worst, rel)
+        assert rel <= 2e-4, (k, rel)        # two fp32 evaluation orders of the same sums (isolated LeakyReLU' flips at round-off-level pre-activations included)
+    assert worst > 0.0                      # the selections really ran different kernels
