@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 P=$(ls -d ntire-2026-*_amd)/csrc
 mkdir -p _diag/obj
 for f in $(grep '^SRCS' $P/Makefile | sed 's/SRCS *:= *//'); do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DLFSR_CONV_DIAG -x hip -c $P/$f -o _diag/obj/$f.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -DLFSR_CONV_DIAG -x hip -c $P/$f -o _diag/obj/$f.o &
   while [ $(jobs -r | wc -l) -ge 4 ]; do sleep 0.2; done
 done
 wait

@@ -6,7 +6,7 @@ P=$(ls -d ntire-2026-*_amd)/csrc
 tag=$1; flags=$2
 mkdir -p _diag/obj_$tag
 for f in $(grep '^SRCS' $P/Makefile | sed 's/SRCS *:= *//'); do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC $flags -x hip -c $P/$f -o _diag/obj_$tag/$f.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize $flags -x hip -c $P/$f -o _diag/obj_$tag/$f.o &
   while [ $(jobs -r | wc -l) -ge 6 ]; do sleep 0.2; done
 done
 wait
