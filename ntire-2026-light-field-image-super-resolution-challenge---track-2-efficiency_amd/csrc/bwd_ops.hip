@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void k_add_inplace(float4* __restrict__ a, con
 // zero halo) are staged in LDS once per chunk, then one phase per destination view v': its 5 x 32 x 64 weights are staged (double-buffered) and
 // wave (pb, cb) computes D[c 16][x' 16] of every line with v_mfma_f32_16x16x4_f32 (A = W^t, B = dE, K = n): a lane holds four consecutive CHANNELS
 // of one pixel, so the accumulate-into-dX epilogue is one 16-B load + one 16-B store per line.  Both operands sit in LDS with the K index permuted
-// (n = 4 s + g stored at 8 g + s), so a lane reads the eight K steps of a (tap, line) pair with two ds_read_b128.
+// (n = 4 s + g stored at 8 g + s), so a lane reads the eight K steps of a (tap, line) pair with two ds_read_b128.  (SQ_LDS_BANK_CONFLICT shows 65 %
+// conflict cycles for these padded-row images; a conflict-free [s / 4][row][g][s % 4] image was built and measured 0.5 % SLOWER on the training step in the
+// same call -- its scattered staging stores cost more than the reads save; LDS is not what bounds this kernel.)
 constexpr int ED_WR = 36, ED_L = 5;
 
 struct EpiDgradArgs {
