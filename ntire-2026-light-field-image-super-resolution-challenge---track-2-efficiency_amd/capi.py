@@ -293,19 +293,33 @@ class DistgSSRRuntime:
         except Exception:
             pass
 
-    def load_state(self, named_tensors, device):
-        """named_tensors: iterable of (key, fp32 CUDA tensor) with the reference's state_dict names."""
+    def load_state(self, named_tensors, device, fanout=None):
+        """named_tensors: iterable of (key, fp32 CUDA tensor) with the reference's state_dict names.
+        fanout: a list of side streams; the pack launches of parameter i then go to stream i % len(fanout), forked from and joined back into the
+        current stream (the ~270 pack kernels of a repack are 4-us launches of 16 blocks each: independent, so they overlap instead of queueing)."""
         nbytes = self.lib.lfsr_distgssr_packed_bytes(self.ctx)
         if self.packed is None or self.packed.device != device:
             self.packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
         check(self.lib.lfsr_distgssr_set_packed(self.ctx, dev_ptr(self.packed), nbytes), "distgssr_set_packed")
+        cur = torch.cuda.current_stream(device)
         st = stream_ptr()
-        for k, t in named_tensors:
+        if fanout:
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            for s in fanout:
+                s.wait_event(fork)
+        for i, (k, t) in enumerate(named_tensors):
             t = t.detach()
             if t.dtype != torch.float32:
                 t = t.float()
             t = t.contiguous()
-            check(self.lib.lfsr_distgssr_load_param(self.ctx, k.encode(), dev_ptr(t, k), t.numel(), st), f"distgssr_load_param({k})")
+            sp = C.c_void_p(fanout[i % len(fanout)].cuda_stream) if fanout else st
+            check(self.lib.lfsr_distgssr_load_param(self.ctx, k.encode(), dev_ptr(t, k), t.numel(), sp), f"distgssr_load_param({k})")
+        if fanout:
+            for s in fanout:
+                e = torch.cuda.Event()
+                e.record(s)
+                cur.wait_event(e)
         check(self.lib.lfsr_distgssr_finalize(self.ctx, st), "distgssr_finalize")
 
     def _workspace(self, B, h, w, device):
