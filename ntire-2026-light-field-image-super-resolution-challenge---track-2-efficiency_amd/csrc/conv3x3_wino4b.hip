@@ -13,7 +13,7 @@
 // v_mfma_f32_16x16x16_bf16 for the cross terms.  Measured against fp64 on random data the six-term sum is 8x closer than an fp32 dot product
 // (3e-8 vs 2.7e-7 relative, tests/test_oracle_vs_golden.py::test_split_bf16_products) -- this is an fp32 kernel whose multiplier is the bf16 array.
 //
-// Why: beside ANY streaming MFMA wave (fp32 or bf16, _diag/micro/micro_bf16.hip) the partner wave's VALU instructions issue every 12-15 cycles
+// Why: beside ANY streaming MFMA wave (fp32 or bf16, tools/micro/micro_bf16.hip) the partner wave's VALU instructions issue every 12-15 cycles
 // instead of 4-7, so the fp32 form (18.4 k MFMA cycles per tile) leaves no room for the producers' transform; the split form needs 7-11 k.
 //
 // Block = 8 waves on one CU, persistent over a contiguous range of 8 x 32-pixel tiles (16 Winograd tiles), specialised as in conv3x3_wino4.hip:

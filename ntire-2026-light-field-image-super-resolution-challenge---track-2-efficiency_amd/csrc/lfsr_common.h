@@ -18,9 +18,9 @@ static inline unsigned lfsr_blocks(long long n, int per) {
   return (unsigned)(b < 1 ? 1 : b);
 }
 // Non-temporal hint on result stores.  Measured on one MI355X (two runs each per call): on the 3x3 conv's output stores alone (buffer_store ... nt,
-// W4_STPOL in conv3x3_wino4.hip) the DistgSSR forward goes 1678.7 -> 1718 patches/s (gpurun_out/r2/bench13_*.json); on the EPI / angular / row-GEMM
+// W4_STPOL in conv3x3_wino4.hip) the DistgSSR forward goes 1678.7 -> 1718 patches/s (profiles/r02_logs/ab_bench_lines.json: bench13_*.json); on the EPI / angular / row-GEMM
 // kernels' stores as well (global_store ... nt through lfsr_store_stream) it FALLS to 1444 (EPIT 668 -> 539, LFT 1331 -> 982 patches/s,
-// gpurun_out/r2/bench14_*.json): those results are re-read by the next kernel while still in the last-level cache.  So only the conv kernel uses the
+// profiles/r02_logs/ab_bench_lines.json: bench14_*.json): those results are re-read by the next kernel while still in the last-level cache.  So only the conv kernel uses the
 // hint; lfsr_store_stream stays for A/B builds.  LFSR_NT_STORES=0 at compile time restores plain stores everywhere.
 #ifndef LFSR_NT_STORES
 #define LFSR_NT_STORES 1

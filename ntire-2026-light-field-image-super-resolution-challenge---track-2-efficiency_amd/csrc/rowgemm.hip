@@ -223,7 +223,7 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
   if (N % 64) return LFSR_E_ARG;
   // LFSR_ROWGEMM=128 (N a multiple of 128: the transformer projections): 128-row x 128-column tiles, one 512-thread block per CU, each wave 32 rows
   // x 64 columns -- X streamed once per 128 output columns, a B fragment feeding two MFMA column tiles.  Measured on EPIT (B = 8, two runs each in
-  // one call, gpurun_out/r2/bench11_epit*.json): 637-639 patches/s against 659-660 for the 64 x 64 form -- one block per CU hides less HBM latency
+  // one call, profiles/r02_logs/ab_bench_lines.json: bench11_epit*.json): 637-639 patches/s against 659-660 for the 64 x 64 form -- one block per CU hides less HBM latency
   // than two; the 64 x 64 form stays the default
   const char* rsel = getenv("LFSR_ROWGEMM");
   const bool wide = N % 128 == 0 && rsel && rsel[0] == '1';

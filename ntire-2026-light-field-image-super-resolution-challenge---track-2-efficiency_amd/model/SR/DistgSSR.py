@@ -131,7 +131,7 @@ class get_model(nn.Module):
                 p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters()):
             torch.cuda.synchronize(device)
             g = torch.cuda.CUDAGraph()
-            nfan = int(os.environ.get("LFSR_PACK_FANOUT", "1"))   # > 1: parallel branches over side streams -- measured SLOWER (27.7 vs 26.0 ms per training step with 8 or 16: gpurun_out/r2/bench25_*.json)
+            nfan = int(os.environ.get("LFSR_PACK_FANOUT", "1"))   # > 1: parallel branches over side streams -- measured SLOWER (27.7 vs 26.0 ms per training step with 8 or 16: profiles/r02_logs/ab_bench_lines.json: bench25_*.json)
             self._pack_streams = [torch.cuda.Stream(device) for _ in range(nfan)] if nfan > 1 else None
             with torch.cuda.graph(g):
                 self._rt.load_state(self.state_dict().items(), device, fanout=self._pack_streams)
