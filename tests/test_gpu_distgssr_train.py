@@ -330,14 +330,18 @@ def test_graph_replayed_repack_equals_eager(monkeypatch):
     assert runs[0][0][-1] < runs[0][0][0]      # and it trains
 
 
-def test_line_form_gradient_kernels_equal_the_gather_forms(monkeypatch):
+@pytest.mark.parametrize("ragged", [False, True])
+def test_line_form_gradient_kernels_equal_the_gather_forms(monkeypatch, ragged):
     """the round-2 backward kernels (Winograd-form 3x3 weight gradient, EPI-line weight / data gradients of EPIConv.0, streaming AngConv.0 data gradient,
     row-GEMM fuse.0 data gradient) against the direct / gather-GEMM forms they replaced, selected by environment variables: the same gradients to fp32
     round-off for every parameter (angRes 5, the ragged-free reduced geometry and a batch of 2)"""
     case, sd, x, _ = model_case("DistgSSR", "a5h8s4")
     A, s = 5, 4
     M = load_plugin()
-    xb = torch.from_numpy(np.concatenate([x, 0.5 * x[:, :, ::-1].copy()], 0)).cuda()
+    if ragged:     # h = 6, w = 9: EPI lines of different lengths in the two passes, odd width, a half-filled 2-row tile pair in the Winograd weight gradient
+        xb = torch.from_numpy(synth_input((2, 1, A * 6, A * 9), seed=11)).cuda()
+    else:
+        xb = torch.from_numpy(np.concatenate([x, 0.5 * x[:, :, ::-1].copy()], 0)).cuda()
     label = torch.from_numpy(synth_input((2, 1, xb.shape[2] * s, xb.shape[3] * s), seed=4)).cuda()
     def grads(env):
         for k in ("LFSR_WGRAD3", "LFSR_WGRAD_EPI", "LFSR_DGRAD_EPI", "LFSR_DGRAD_ANG", "LFSR_NO_ROWGEMM"):
