@@ -31,6 +31,9 @@ struct EpiArgs {
   float* TH; float* TV;   // optional (lines*len, 32): post-LeakyReLU stage-1 activations saved for backward
   int B, A, H, W;
   int tilesH, tilesV;   // tiles per pass; blockIdx.x < tilesH -> horizontal
+  int xcd_swz;          // 1: XCD-aware block order (needs gridDim.x % 8 == 0)
+  int tpiH, tpiV;       // > 0: blocks are ordered ITEM by item (tpiH horizontal tiles of batch item b, then its tpiV vertical tiles), so an item's
+                        // second pass reads its 25 view images while they are still in the last-level caches; 0: all horizontal tiles, then all vertical ones
   float slope;
 };
 
@@ -49,8 +52,18 @@ __global__ __launch_bounds__(512) void k_epi_fused(EpiArgs p) {
   const int half = lane >> 5, l31 = lane & 31;
   const int HW = p.H * p.W;
 
-  const bool vert = (int)blockIdx.x >= p.tilesH;
-  const int tile = vert ? blockIdx.x - p.tilesH : blockIdx.x;
+  bool vert; int tile;
+  if (p.tpiH > 0) {
+    // consecutive workgroups go to consecutive XCDs (8 per chip): with xcd_swz the blocks of one XCD walk a CONTIGUOUS range of items, so both passes of an
+    // item share one L2 instead of every XCD reading every item twice
+    const int bid = p.xcd_swz ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int per = p.tpiH + p.tpiV, item = bid / per, r = bid - item * per;
+    vert = r >= p.tpiH;
+    tile = vert ? item * p.tpiV + (r - p.tpiH) : item * p.tpiH + r;
+  } else {
+    vert = (int)blockIdx.x >= p.tilesH;
+    tile = vert ? blockIdx.x - p.tilesH : blockIdx.x;
+  }
   const int len = vert ? p.H : p.W;                 // positions along the line
   const int across = vert ? p.W : p.H;              // lines per (b, u|v) group
   const int nlines = p.B * A * across;
@@ -254,8 +267,18 @@ __global__ __launch_bounds__(512) void k_epi_wino5(EpiArgs p) {
   const int half = lane >> 5, l31 = lane & 31, l15 = lane & 15, g = lane >> 4;
   const int HW = p.H * p.W;
 
-  const bool vert = (int)blockIdx.x >= p.tilesH;
-  const int tile = vert ? blockIdx.x - p.tilesH : blockIdx.x;
+  bool vert; int tile;
+  if (p.tpiH > 0) {
+    // consecutive workgroups go to consecutive XCDs (8 per chip): with xcd_swz the blocks of one XCD walk a CONTIGUOUS range of items, so both passes of an
+    // item share one L2 instead of every XCD reading every item twice
+    const int bid = p.xcd_swz ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int per = p.tpiH + p.tpiV, item = bid / per, r = bid - item * per;
+    vert = r >= p.tpiH;
+    tile = vert ? item * p.tpiV + (r - p.tpiH) : item * p.tpiH + r;
+  } else {
+    vert = (int)blockIdx.x >= p.tilesH;
+    tile = vert ? blockIdx.x - p.tilesH : blockIdx.x;
+  }
   const int len = vert ? p.H : p.W;
   const int across = vert ? p.W : p.H;
   const int nlines = p.B * A * across;
@@ -488,6 +511,11 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   p.tilesV = (which & 2) ? (B * A * w + LINES - 1) / LINES : 0;
   int grid = p.tilesH + p.tilesV;
   if (grid <= 0) return LFSR_E_ARG;
+  // item-major block order when both passes run and an item's lines fill whole tiles (LFSR_EPI_ORDER=pass keeps pass-major order: A/B runs)
+  {
+    const char* osel = getenv("LFSR_EPI_ORDER");
+    if (which == 3 && (A * h) % LINES == 0 && (A * w) % LINES == 0 && !(osel && osel[0] == 'p')) { p.tpiH = A * h / LINES; p.tpiV = A * w / LINES; p.xcd_swz = (grid % 8 == 0) && !(osel && osel[0] == 'i'); }
+  }
   // A = 5: stage 1 in Winograd F(2,5) form (the pack appended to the direct one by lfsr_pack_conv_weight); LFSR_EPI=direct keeps the direct form (A/B runs)
   const char* esel = getenv("LFSR_EPI");
   p.W1u = w1_packed + 25 * 32 * 64;
