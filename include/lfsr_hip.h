@@ -148,6 +148,10 @@ int lfsr_distgssr_set_packed(lfsr_distgssr* ctx, void* packed, size_t bytes);
 int lfsr_distgssr_load_param(lfsr_distgssr* ctx, const char* key, const float* data, size_t numel, void* stream);
 /* after all params are loaded: folds the upsample head; returns LFSR_E_ARG if a parameter is missing */
 int lfsr_distgssr_finalize(lfsr_distgssr* ctx, void* stream);
+/* optional, before a round of lfsr_distgssr_load_param calls (a training step's repack): the packs are recorded instead of launched one by one and
+ * lfsr_distgssr_finalize launches them, one kernel per pack kind (the descriptor table lives in a small device buffer owned by the context and is
+ * re-uploaded only when a parameter's address changed).  The data pointers passed to load_param must stay valid until finalize's work has run. */
+int lfsr_distgssr_begin_batched_load(lfsr_distgssr* ctx);
 size_t lfsr_distgssr_workspace_bytes(const lfsr_distgssr* ctx, int B, int h, int w);
 /* x (B,1,A*h,A*w) -> out (B,1,A*h*s,A*w*s), both NCHW SAI mosaics, fp32 */
 int lfsr_distgssr_forward(lfsr_distgssr* ctx, const float* x, float* out, int B, int h, int w,

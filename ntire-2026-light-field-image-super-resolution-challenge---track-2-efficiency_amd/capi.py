@@ -45,6 +45,7 @@ SIGNATURES = {
     "lfsr_distgssr_set_packed": (c_i, [c_p, c_p, c_sz]),
     "lfsr_distgssr_load_param": (c_i, [c_p, C.c_char_p, c_p, c_sz, c_p]),
     "lfsr_distgssr_finalize": (c_i, [c_p, c_p]),
+    "lfsr_distgssr_begin_batched_load": (c_i, [c_p]),
     "lfsr_distgssr_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "lfsr_distgssr_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
     "lfsr_distgssr_forward_taps": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, C.POINTER(c_p), c_p]),
@@ -293,7 +294,7 @@ class DistgSSRRuntime:
         except Exception:
             pass
 
-    def load_state(self, named_tensors, device, fanout=None):
+    def load_state(self, named_tensors, device, fanout=None, batched=False):
         """named_tensors: iterable of (key, fp32 CUDA tensor) with the reference's state_dict names.
         fanout: a list of side streams; the pack launches of parameter i then go to stream i % len(fanout), forked from and joined back into the
         current stream (the ~270 pack kernels of a repack are 4-us launches of 16 blocks each: independent, so they overlap instead of queueing)."""
@@ -303,6 +304,9 @@ class DistgSSRRuntime:
         check(self.lib.lfsr_distgssr_set_packed(self.ctx, dev_ptr(self.packed), nbytes), "distgssr_set_packed")
         cur = torch.cuda.current_stream(device)
         st = stream_ptr()
+        keep = []
+        if batched:     # one launch per pack kind at finalize (the tensors handed over must stay alive until then: `keep`)
+            check(self.lib.lfsr_distgssr_begin_batched_load(self.ctx), "distgssr_begin_batched_load")
         if fanout:
             fork = torch.cuda.Event()
             fork.record(cur)
@@ -314,6 +318,7 @@ class DistgSSRRuntime:
                 t = t.float()
             t = t.contiguous()
             sp = C.c_void_p(fanout[i % len(fanout)].cuda_stream) if fanout else st
+            keep.append(t)
             check(self.lib.lfsr_distgssr_load_param(self.ctx, k.encode(), dev_ptr(t, k), t.numel(), sp), f"distgssr_load_param({k})")
         if fanout:
             for s in fanout:

@@ -789,7 +789,30 @@ __global__ __launch_bounds__(256) void k_pack_conv3_raw(const float* __restrict_
   emit_wino4(g, n, k, out);
 }
 
+// ... for a whole table of weights in one launch (blockIdx.y = the weight)
+__global__ __launch_bounds__(256) void k_pack_conv3_raw_batch(const LfsrPackDesc* __restrict__ tab) {
+  const LfsrPackDesc d = tab[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (n, k)
+  if (i >= 64 * 64) return;
+  const int n = i >> 6, k = i & 63;
+  double g[3][3];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float v = d.flip ? d.src[(k * 64 + n) * 9 + (8 - t)] : d.src[(n * 64 + k) * 9 + t];
+    d.dst[(t * 64 + n) * 64 + k] = v;
+    g[t / 3][t % 3] = (double)v;
+  }
+  emit_wino4(g, n, k, d.dst2);
+}
+
 }  // namespace
+
+int lfsr_pack_conv3_raw_wino4_batch(const LfsrPackDesc* table_dev, int n, hipStream_t st) {
+  if (!table_dev || n <= 0) return n == 0 ? LFSR_OK : LFSR_E_ARG;
+  hipLaunchKernelGGL(k_pack_conv3_raw_batch, dim3(16, (unsigned)n), dim3(256), 0, st, table_dev);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
 
 int lfsr_pack_conv3_raw_wino4(const float* w_raw, float* direct_out, float* wino4_out, int transposed, hipStream_t st) {
   if (!w_raw || !direct_out || !wino4_out) return LFSR_E_ARG;

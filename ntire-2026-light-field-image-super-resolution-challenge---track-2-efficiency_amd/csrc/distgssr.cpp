@@ -1,6 +1,7 @@
 // Host driver for the DistgSSR forward (get_model.forward, model/SR/DistgSSR.py:29-36) on VCL buffers.
 // Pure host code above the C-ABI operator entry points: owns the packed-weight table keyed by the
 // reference's state_dict names and the launch sequence; allocates nothing on the device.
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -30,6 +31,12 @@ struct lfsr_distgssr {
   size_t packed_floats = 0, off_wf = 0, off_bf = 0;
   float* packed = nullptr;
   bool finalized = false;
+  // batched repack (lfsr_distgssr_begin_batched_load): load_param records one descriptor per pack instead of launching it; finalize uploads the
+  // table when it changed (parameter addresses are stable across optimizer steps) and launches one kernel per pack kind
+  bool batch_mode = false;
+  std::vector<LfsrPackDesc> d_gen, d_c3, d_epi, uploaded;
+  LfsrPackDesc* table_dev = nullptr;
+  size_t table_cap = 0;
   bool profiling = false;
   struct Ev { int cls; hipEvent_t a, b; };
   bool profile_all = true;
@@ -100,7 +107,15 @@ void lfsr_distgssr_destroy(lfsr_distgssr* c) {
   if (!c) return;
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto e : c->free_evs) (void)hipEventDestroy(e);
+  if (c->table_dev) (void)hipFree(c->table_dev);
   delete c;
+}
+
+int lfsr_distgssr_begin_batched_load(lfsr_distgssr* c) {
+  if (!c) return LFSR_E_ARG;
+  c->batch_mode = true;
+  c->d_gen.clear(); c->d_c3.clear(); c->d_epi.clear();
+  return LFSR_OK;
 }
 
 int lfsr_distgssr_profile(lfsr_distgssr* c, int enable) {
@@ -151,6 +166,22 @@ int lfsr_distgssr_load_param(lfsr_distgssr* c, const char* key, const float* dat
   if (sl.raw) {
     hipError_t e = hipMemcpyAsync(c->packed + sl.off, data, numel * sizeof(float), hipMemcpyDeviceToDevice, lfsr_stream(stream));
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
+  } else if (c->batch_mode && (lfsr_conv3_variant_mask() == LFSR_W_WINO4 || !(sl.O == 64 && sl.C == 64 && sl.T == 9))) {
+    // record the packs; lfsr_distgssr_finalize launches them, one kernel per kind (3x3 weights with another kernel selection keep the eager path below)
+    auto pad32 = [](int v) { return (v + 31) / 32 * 32; };
+    float* dst = c->packed + sl.off;
+    float* tdst = c->packed + sl.offT;
+    const bool c3 = sl.O == 64 && sl.C == 64 && sl.T == 9 && sl.perm == 0;
+    if (c3) c->d_c3.push_back(LfsrPackDesc{data, dst, dst + LFSR_CONV3_DIRECT_FLOATS + LFSR_CONV3_WINO2_FLOATS, 0, 64, 64, 9, 64, 0, 0, 0});
+    else {
+      c->d_gen.push_back(LfsrPackDesc{data, dst, nullptr, 0, sl.O, sl.C, sl.T, pad32(sl.O), sl.perm, sl.ch, 0});
+      if (sl.O == 32 && sl.C == 64 && sl.T == 25 && sl.perm == 0) c->d_epi.push_back(LfsrPackDesc{dst, dst + 25 * 32 * 64, nullptr, 0, 32, 64, 25, 32, 0, 0, 0});
+    }
+    if (sl.kindT == 1 && c3) c->d_c3.push_back(LfsrPackDesc{data, tdst, tdst + LFSR_CONV3_DIRECT_FLOATS + LFSR_CONV3_WINO2_FLOATS, 0, 64, 64, 9, 64, 0, 0, 1});
+    else if (sl.kindT == 1) c->d_gen.push_back(LfsrPackDesc{data, tdst, nullptr, 1, sl.O, sl.C, sl.T, pad32(sl.C), 0, 0, 1});
+    if (sl.kindT == 2) c->d_gen.push_back(LfsrPackDesc{data, tdst, nullptr, 1, sl.O, sl.C, sl.T, pad32(sl.C), 0, 0, 0});
+    if (sl.kindT == 3) c->d_gen.push_back(LfsrPackDesc{data, tdst, nullptr, 2, sl.O, sl.C, 1, pad32(sl.C), 1, 16, 0});
+    if (sl.kindT == 4) c->d_gen.push_back(LfsrPackDesc{data, tdst, nullptr, 2, sl.O, sl.C, 1, pad32(sl.C), 0, 32, 0});
   } else {
     const int vmask = lfsr_conv3_variant_mask();   // only the Winograd-domain copies the selected 3x3 kernel reads (this runs once per weight and training step)
     int rc = lfsr_pack_conv_weight_m(data, c->packed + sl.off, sl.O, sl.C, sl.T, sl.perm, sl.ch, vmask, stream);
@@ -170,6 +201,31 @@ int lfsr_distgssr_finalize(lfsr_distgssr* c, void* stream) {
   if (!c || !c->packed) return LFSR_E_ARG;
   for (auto& kv : c->slots)
     if (!kv.second.loaded) return LFSR_E_ARG;
+  if (c->batch_mode) {
+    c->batch_mode = false;
+    std::vector<LfsrPackDesc> all(c->d_gen);
+    all.insert(all.end(), c->d_c3.begin(), c->d_c3.end());
+    all.insert(all.end(), c->d_epi.begin(), c->d_epi.end());
+    bool same = all.size() == c->uploaded.size();
+    for (size_t i = 0; same && i < all.size(); ++i) same = memcmp(&all[i], &c->uploaded[i], sizeof(LfsrPackDesc)) == 0;
+    if (!same) {
+      if (all.size() > c->table_cap) {
+        if (c->table_dev) (void)hipFree(c->table_dev);
+        c->table_dev = nullptr; c->table_cap = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->table_dev), (all.size() + 64) * sizeof(LfsrPackDesc));
+        if (e != hipSuccess) return LFSR_HIP_ERR(e);
+        c->table_cap = all.size() + 64;
+      }
+      c->uploaded = all;   // (the copy's source outlives it; a pageable-memory copy is staged before the call returns)
+      hipError_t e = hipMemcpyAsync(c->table_dev, c->uploaded.data(), all.size() * sizeof(LfsrPackDesc), hipMemcpyHostToDevice, lfsr_stream(stream));
+      if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    }
+    const int ng = (int)c->d_gen.size(), n3 = (int)c->d_c3.size(), ne = (int)c->d_epi.size();
+    int rcb = lfsr_pack_generic_batch(c->table_dev, ng, lfsr_stream(stream));
+    if (!rcb) rcb = lfsr_pack_conv3_raw_wino4_batch(c->table_dev + ng, n3, lfsr_stream(stream));
+    if (!rcb) rcb = lfsr_pack_epi_wino_batch(c->table_dev + ng + n3, ne, lfsr_stream(stream));   // reads the direct packs written by the first launch
+    if (rcb) return rcb;
+  }
   int rc = lfsr_fold_head(c->w("upsample.0.weight"), c->w("upsample.0.bias"), c->w("upsample.2.weight"),
                           c->packed + c->off_wf, c->packed + c->off_bf, 64, c->s, stream);
   if (rc) return rc;

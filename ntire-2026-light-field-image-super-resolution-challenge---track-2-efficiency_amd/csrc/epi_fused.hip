@@ -467,7 +467,35 @@ __global__ __launch_bounds__(256) void k_pack_epi_wino(const float* __restrict__
   }
 }
 
+__global__ __launch_bounds__(256) void k_pack_epi_wino_batch(const LfsrPackDesc* __restrict__ tab) {
+  const LfsrPackDesc d = tab[blockIdx.y];
+  const float* __restrict__ w1 = d.src;
+  float* __restrict__ out = d.dst;
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (v', n, c)
+  if (i >= 5 * 32 * 64) return;
+  const int c = i & 63, n = (i >> 6) & 31, v = i >> 11;
+  double gk[5];
+#pragma unroll
+  for (int dx = 0; dx < 5; ++dx) gk[dx] = (double)w1[((5 * dx + v) * 32 + n) * 64 + c];
+  const double G[6][5] = {{1.0 / 4, 0, 0, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6, 1.0 / 3, 2.0 / 3}, {1.0 / 24, -1.0 / 12, 1.0 / 6, -1.0 / 3, 2.0 / 3}, {0, 0, 0, 0, 1.0}};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    double u = 0.0;
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) u += G[q][dx] * gk[dx];
+    out[((v * 6 + q) * 32 + n) * 64 + c] = (float)u;
+  }
+}
+
 }  // namespace
+
+int lfsr_pack_epi_wino_batch(const LfsrPackDesc* table_dev, int n, hipStream_t st) {
+  if (!table_dev || n <= 0) return n == 0 ? LFSR_OK : LFSR_E_ARG;
+  hipLaunchKernelGGL(k_pack_epi_wino_batch, dim3(40, (unsigned)n), dim3(256), 0, st, table_dev);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
 
 int lfsr_pack_epi_wino(const float* w1_direct_packed, float* out, hipStream_t st) {
   if (!w1_direct_packed || !out) return LFSR_E_ARG;

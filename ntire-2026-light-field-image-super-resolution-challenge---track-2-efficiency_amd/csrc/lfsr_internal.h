@@ -50,6 +50,12 @@ int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st);   //
 // The selection is read when weights are packed AND when a conv is launched: set it before loading a model.
 enum { LFSR_W_WINO2 = 1, LFSR_W_WINO4 = 2, LFSR_W_WINO4S = 4, LFSR_W_WINO4B = 8, LFSR_W_ALL = 15 };
 int lfsr_conv3_variant_mask();
+// Batched repack (training: every weight is repacked every step; one launch per pack KIND with a device-side descriptor table instead of one 4-us
+// launch per weight and layout).  kind 0: lfsr_pack_conv_weight's direct pack (perm 0 / 1), 1: lfsr_pack_weight_T (flip = taps reversed), 2: lfsr_pack_weight_chunkT.
+struct LfsrPackDesc { const float* src; float* dst; float* dst2; int kind, O, C, T, Npad, perm, ch, flip; };
+int lfsr_pack_generic_batch(const LfsrPackDesc* table_dev, int n, hipStream_t st);                    // kinds 0..2 (pack_batch.hip)
+int lfsr_pack_conv3_raw_wino4_batch(const LfsrPackDesc* table_dev, int n, hipStream_t st);            // src -> dst (direct) + dst2 (F(4x4) copy); flip = transposed form
+int lfsr_pack_epi_wino_batch(const LfsrPackDesc* table_dev, int n, hipStream_t st);                   // src = the direct pack, dst = its F(2,5) copy
 int lfsr_pack_conv3_raw_wino4(const float* w_raw, float* direct_out, float* wino4_out, int transposed, hipStream_t st);   // direct + F(4x4) copies in one launch
 int lfsr_pack_wino_m(const float* direct_packed, float* out, int mask, hipStream_t st);
 int lfsr_pack_conv_weight_m(const float* w, float* packed, int O, int C, int taps, int perm, int ch, int mask, void* stream);

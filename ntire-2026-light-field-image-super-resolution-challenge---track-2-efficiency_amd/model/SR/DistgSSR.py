@@ -115,11 +115,19 @@ class get_model(nn.Module):
         return self._rt
 
     def _repack(self, device):
-        """Hand the current parameter values to the HIP library.  An optimizer step changes values, not addresses: the ~400 small pack
-        launches (137 parameters x their layouts) are then replayed from ONE captured graph instead of being re-issued through 137 ctypes
-        calls (LFSR_PACK_GRAPH=0 disables; any change of a parameter's address falls back to the eager path and re-captures)."""
+        """Hand the current parameter values to the HIP library.  An optimizer step changes values, not addresses.  Default: the packs are recorded
+        into a device-side descriptor table (re-uploaded only when an address changed) and run as one launch per pack kind.  LFSR_PACK_BATCH=0: the
+        ~280 small pack launches are replayed from ONE captured graph instead (LFSR_PACK_GRAPH=0: re-issued one by one; any change of a parameter's
+        address falls back to the eager path and re-captures)."""
         import os
         ptrs = (device, tuple(p.data_ptr() for p in self.parameters()))
+        fp32 = all(p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters())
+        if fp32 and os.environ.get("LFSR_PACK_BATCH", "1") != "0":
+            # one launch per pack kind from a device-side descriptor table (re-uploaded only when an address changed): ~280 4-us launches -> 4
+            self._pack_graph = None
+            self._rt.load_state(self.state_dict().items(), device, batched=True)
+            self._pack_ptrs = ptrs
+            return
         if self._pack_graph is not None and ptrs == self._pack_ptrs:
             self._pack_graph.replay()
             return
@@ -127,8 +135,7 @@ class get_model(nn.Module):
         self._rt.load_state(self.state_dict().items(), device)
         self._pack_eager_count = self._pack_eager_count + 1 if ptrs == self._pack_ptrs else 1
         self._pack_ptrs = ptrs
-        if self._pack_eager_count >= 2 and os.environ.get("LFSR_PACK_GRAPH", "1") != "0" and all(
-                p.dtype == torch.float32 and p.is_contiguous() for p in self.parameters()):
+        if self._pack_eager_count >= 2 and os.environ.get("LFSR_PACK_GRAPH", "1") != "0" and fp32:
             torch.cuda.synchronize(device)
             g = torch.cuda.CUDAGraph()
             nfan = int(os.environ.get("LFSR_PACK_FANOUT", "1"))   # > 1: parallel branches over side streams -- measured SLOWER (27.7 vs 26.0 ms per training step with 8 or 16: profiles/r02_logs/ab_bench_lines.json: bench25_*.json)

@@ -307,27 +307,32 @@ def test_amp_loop_shape_gradscaler():
     assert diff / sum(p.numel() for p in nets[0].parameters()) < 1e-3
 
 
-def test_graph_replayed_repack_equals_eager(monkeypatch):
-    """After an optimizer step only parameter VALUES change: the weight repack is replayed from one captured graph (model/SR/DistgSSR.py:_repack).
-    Five steps with the replayed repack equal five steps with the eager one, bit for bit."""
+def test_repack_modes_equal_eager(monkeypatch):
+    """After an optimizer step only parameter VALUES change (model/SR/DistgSSR.py:_repack): the weight repack runs as ONE launch per pack kind from a
+    device-side descriptor table (default), or is replayed from a captured graph (LFSR_PACK_BATCH=0), or is re-issued launch by launch
+    (LFSR_PACK_BATCH=0 LFSR_PACK_GRAPH=0).  Five training steps in each mode are equal bit for bit -- for angRes 3 (generic 3x3 packs) and angRes 5
+    (the F(2,5) EPI pack as well)."""
     from lfsr_amd.train_step import train_step
-    A, h, w, s, B = 3, 6, 8, 2, 2
-    case, sd, x, _ = model_case("DistgSSR", "a3h6w8s2")
-    label = torch.from_numpy(synth_input((B, 1, A * h * s, A * w * s), seed=2)).cuda()
-    xa = torch.from_numpy(x).cuda()
-    M = load_plugin()
-    runs = []
-    for graph in ("1", "0"):
-        monkeypatch.setenv("LFSR_PACK_GRAPH", graph)
-        net = build(M, A, s, sd)
-        opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
-        crit = M.get_loss(None)
-        losses = [float(train_step(net, crit, opt, xa, label)[0]) for _ in range(5)]
-        assert (net._pack_graph is not None) == (graph == "1")
-        runs.append((losses, [p.detach().clone() for p in net.parameters()]))
-    assert runs[0][0] == runs[1][0]
-    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
-    assert runs[0][0][-1] < runs[0][0][0]      # and it trains
+    for tag, A, s in (("a3h6w8s2", 3, 2), ("a5h8s4", 5, 4)):
+        case, sd, x, _ = model_case("DistgSSR", tag)
+        xa = torch.from_numpy(x).cuda()
+        label = torch.from_numpy(synth_input((xa.shape[0], 1, xa.shape[2] * s, xa.shape[3] * s), seed=2)).cuda()
+        M = load_plugin()
+        runs = []
+        for batch, graph in (("1", "1"), ("0", "1"), ("0", "0")):
+            monkeypatch.setenv("LFSR_PACK_BATCH", batch)
+            monkeypatch.setenv("LFSR_PACK_GRAPH", graph)
+            net = build(M, A, s, sd)
+            opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
+            crit = M.get_loss(None)
+            losses = [float(train_step(net, crit, opt, xa, label)[0]) for _ in range(5)]
+            assert (net._pack_graph is not None) == (batch == "0" and graph == "1")
+            runs.append((losses, [p.detach().clone() for p in net.parameters()]))
+        for r in runs[1:]:
+            assert runs[0][0] == r[0], tag
+            assert all(torch.equal(a, b) for a, b in zip(runs[0][1], r[1])), tag
+        assert runs[0][0][-1] < runs[0][0][0]      # and it trains
+    monkeypatch.delenv("LFSR_PACK_BATCH"); monkeypatch.delenv("LFSR_PACK_GRAPH")
 
 
 @pytest.mark.parametrize("ragged", [False, True])
