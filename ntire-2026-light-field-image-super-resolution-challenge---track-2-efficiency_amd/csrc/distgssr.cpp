@@ -521,8 +521,13 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
       RC(wgrad3(p + "fuse.2.weight", t.FZ[i], gy, 64));
       RC(dgrad3(gy, 64, p + "fuse.2.weight", t.dF, nullptr, nullptr, t.FZ[i], 64));
       // fuse.0 : FZ = lrelu(1x1(CAT))
-      RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.dF, 64, 0, t.CAT[i], 144, 0, t.P[0], npix, 64, 144, 1, h, w, 1, st));
-      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 1, 144), nullptr, 0, G(p + "fuse.0.weight"), 64, 144, 1, 0, 0, 0, 0, 0, st));
+      {   // streaming kernel (every row of dF and CAT read once, one slab per block); else the generic split-K kernel
+        int rc5 = lfsr_wgrad_pw144_launch(t.dF, 64, 0, t.CAT[i], 144, 0, t.P[0], npix, st);
+        int slabs = lfsr_wgrad_pw144_blocks(npix);
+        if (rc5 == LFSR_E_ARG) { rc5 = lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.dF, 64, 0, t.CAT[i], 144, 0, t.P[0], npix, 64, 144, 1, h, w, 1, st); slabs = lfsr_wgrad_splits(npix, 1, 144); }
+        RC(rc5);
+        RC(lfsr_wgrad_reduce(t.P[0], slabs, nullptr, 0, G(p + "fuse.0.weight"), 64, 144, 1, 0, 0, 0, 0, 0, st));
+      }
       {
         LfsrGemm q{};
         q.in_mode = LFSR_IN_SAME; q.out_mode = LFSR_OUT_SAME; q.cin = 64; q.X = t.dF; q.x_stride = 64; q.Wp = c->wT(p + "fuse.0.weight");

@@ -126,6 +126,8 @@ int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_
                       float* P, int M, int N, int K, int A, int h, int w, int ntaps, hipStream_t st);
 // halo-tile 3x3 conv weight gradient: partials P [lfsr_wgrad_conv3_blocks()][9][64][64], reduce with nsplit = that count
 int lfsr_wgrad_conv3_blocks(int n_img, int h, int w);
+int lfsr_wgrad_pw144_blocks(int M);
+int lfsr_wgrad_pw144_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P, int M, hipStream_t st);
 int lfsr_wgrad_epi0_blocks(int B, int A, int h, int w, int vert);
 int lfsr_ang0_dgrad_launch(const float* dA16, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, hipStream_t st);
 int lfsr_epi0_dgrad_launch(const float* dE, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, int vert, hipStream_t st);

@@ -476,6 +476,81 @@ __global__ __launch_bounds__(512) void k_wgrad_epi0_lines(WgradEpiArgs p) {
     for (int r = 0; r < 4; ++r) out[((long long)t * 32 + nh * 16 + 4 * g + r) * 64 + cq * 16 + l15] = acc[t][r];
 }
 
+// ---- 1x1 weight gradient of fuse.0 (64 outputs, K = 144 inputs), streaming form --------------------------------------------------------------
+// dW[n][k] = sum_m dY[m][n] X[m][k].  The generic kernel above splits K into 64-wide slices (grid.z) and re-reads dY for each: 3 x 52 MB + 118 MB
+// at the training geometry.  Here a persistent 512-thread block walks 64-row chunks (double-buffered in LDS, one barrier per chunk) and reads each
+// row of dY and X once; wave (nq, kq) owns the 32 x 32 block (n half, k tile kq of 0..3) and waves 0..3 also one 16 x 16 block of the ragged tail
+// k = 128..143 -- all accumulators alive across the block's chunks, one [Npad 64][K 144] partial slab per block at the end.
+constexpr int PW_ROWS = 64, PW_GS = 68, PW_XS = 148;   // LDS row strides (floats): 68 / 148 = 4 mod 32 banks -> the two pixel halves of an MFMA read disjoint banks
+
+struct WgradPwArgs {
+  const float* G; int g_stride; int g_choff;
+  const float* X; int x_stride; int x_choff;
+  float* P;        // [gridDim.x][64][144]
+  int M;
+};
+
+__global__ __launch_bounds__(512) void k_wgrad_pw144(WgradPwArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smp[];
+  constexpr int BUF = PW_ROWS * (PW_GS + PW_XS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nq = wave >> 2, kq = wave & 3;
+  const int half = lane >> 5, l31 = lane & 31, l15 = lane & 15, g4 = lane >> 4;
+  const int nchunks = (p.M + PW_ROWS - 1) / PW_ROWS;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4 acct = {0.f, 0.f, 0.f, 0.f};     // waves 0..3: block (n = 16 wave .. +15, k = 128 .. 143)
+  // staging slots: dY 64 rows x 16 float4, X 64 rows x 36 float4 = 3328 float4 over 512 threads: 2 + 5 (the last partly)
+  float4 rg[2], rx[5];
+  auto prefetch = [&](int chunk) {
+    const long long m0 = (long long)chunk * PW_ROWS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, r = idx >> 4, c = idx & 15;
+      const long long m = m0 + r;
+      rg[i] = m < p.M ? *reinterpret_cast<const float4*>(p.G + m * p.g_stride + p.g_choff + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int idx = tid + 512 * i, r = idx / 36, c = idx - r * 36;
+      const long long m = m0 + r;
+      rx[i] = (idx < PW_ROWS * 36 && m < p.M) ? *reinterpret_cast<const float4*>(p.X + m * p.x_stride + p.x_choff + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  int chunk = blockIdx.x, it = 0;
+  if (chunk < nchunks) prefetch(chunk);
+  for (; chunk < nchunks; chunk += gridDim.x, ++it) {
+    float* const sG = smp + (it & 1) * BUF;
+    float* const sX = sG + PW_ROWS * PW_GS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int idx = tid + 512 * i; *reinterpret_cast<float4*>(sG + (idx >> 4) * PW_GS + (idx & 15) * 4) = rg[i]; }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const int idx = tid + 512 * i, r = idx / 36, c = idx - r * 36; if (idx < PW_ROWS * 36) *reinterpret_cast<float4*>(sX + r * PW_XS + c * 4) = rx[i]; }
+    __syncthreads();   // (the only barrier of a chunk: the other buffer was last read before the previous chunk's barrier)
+    if (chunk + (int)gridDim.x < nchunks) prefetch(chunk + gridDim.x);
+    const float* gp = sG + half * PW_GS + nq * 32 + l31;
+    const float* xp = sX + half * PW_XS + kq * 32 + l31;
+#pragma unroll 8
+    for (int mm = 0; mm < PW_ROWS; mm += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[mm * PW_GS], xp[mm * PW_XS], acc, 0, 0, 0);
+    if (wave < 4) {
+      const float* gt = sG + g4 * PW_GS + wave * 16 + l15;
+      const float* xt = sX + g4 * PW_XS + 128 + l15;
+#pragma unroll 4
+      for (int mm = 0; mm < PW_ROWS; mm += 4)
+        acct = __builtin_amdgcn_mfma_f32_16x16x4f32(gt[mm * PW_GS], xt[mm * PW_XS], acct, 0, 0, 0);
+    }
+  }
+  float* out = p.P + (long long)blockIdx.x * 64 * 144;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[(nq * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 144 + kq * 32 + l31] = acc[r];
+  if (wave < 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(wave * 16 + 4 * g4 + r) * 144 + 128 + l15] = acct[r];
+  }
+}
+
 // sum partial slabs in split order and scatter to the PyTorch layout (O, C, T): inverse of k_pack_weight.
 // P2 (optional) is a second partial set with the same geometry (the vertical EPI pass shares its weights).
 __global__ __launch_bounds__(512) void k_wgrad_reduce(const float* __restrict__ P, int nsplit, const float* __restrict__ P2, int nsplit2,
@@ -675,6 +750,33 @@ int lfsr_wgrad_epi0_launch(const float* dE, const float* dE_v, const float* X, i
   p.g_bytes = (int)((long long)B * A * h * w * 32 * 4); p.x_bytes = (int)((long long)B * A * A * h * w * x_stride * 4);
   p.B = B; p.A = A; p.H = h; p.W = w; p.vert = vert;
   hipLaunchKernelGGL(k_wgrad_epi0_lines<5>, dim3((unsigned)lfsr_wgrad_epi0_blocks(B, A, h, w, vert)), dim3(512), smem, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+
+// fuse.0-shaped 1x1 weight gradient (N = 64, K = 144): one slab per block; LFSR_E_ARG = not covered.  LFSR_WGRAD_PW=gather keeps the generic kernel.
+int lfsr_wgrad_pw144_blocks(int M) {
+  const int nchunks = (M + PW_ROWS - 1) / PW_ROWS;
+  return nchunks < 256 ? nchunks : 256;
+}
+
+int lfsr_wgrad_pw144_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P, int M, hipStream_t st) {
+  if (!G || !X || !P || M <= 0 || ((g_stride | g_choff | x_stride | x_choff) & 3) || g_stride < g_choff + 64 || x_stride < x_choff + 144) return LFSR_E_ARG;
+  const char* sel = getenv("LFSR_WGRAD_PW");
+  if (sel && sel[0] == 'g') return LFSR_E_ARG;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  constexpr int smem = 2 * PW_ROWS * (PW_GS + PW_XS) * 4;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_pw144), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  WgradPwArgs p{};
+  p.G = G; p.g_stride = g_stride; p.g_choff = g_choff; p.X = X; p.x_stride = x_stride; p.x_choff = x_choff; p.P = P; p.M = M;
+  hipLaunchKernelGGL(k_wgrad_pw144, dim3((unsigned)lfsr_wgrad_pw144_blocks(M)), dim3(512), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }

@@ -349,7 +349,7 @@ def test_line_form_gradient_kernels_equal_the_gather_forms(monkeypatch, ragged):
         xb = torch.from_numpy(np.concatenate([x, 0.5 * x[:, :, ::-1].copy()], 0)).cuda()
     label = torch.from_numpy(synth_input((2, 1, xb.shape[2] * s, xb.shape[3] * s), seed=4)).cuda()
     def grads(env):
-        for k in ("LFSR_WGRAD3", "LFSR_WGRAD_EPI", "LFSR_DGRAD_EPI", "LFSR_DGRAD_ANG", "LFSR_NO_ROWGEMM"):
+        for k in ("LFSR_WGRAD3", "LFSR_WGRAD_EPI", "LFSR_DGRAD_EPI", "LFSR_DGRAD_ANG", "LFSR_WGRAD_PW", "LFSR_NO_ROWGEMM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -358,8 +358,8 @@ def test_line_form_gradient_kernels_equal_the_gather_forms(monkeypatch, ragged):
         torch.cuda.synchronize()
         return {k: p.grad.detach().double().cpu() for k, p in net.named_parameters()}
     new = grads({})
-    old = grads({"LFSR_WGRAD3": "direct", "LFSR_WGRAD_EPI": "gather", "LFSR_DGRAD_EPI": "gather", "LFSR_DGRAD_ANG": "gather", "LFSR_NO_ROWGEMM": "1"})
-    for k in ("LFSR_WGRAD3", "LFSR_WGRAD_EPI", "LFSR_DGRAD_EPI", "LFSR_DGRAD_ANG", "LFSR_NO_ROWGEMM"):
+    old = grads({"LFSR_WGRAD3": "direct", "LFSR_WGRAD_EPI": "gather", "LFSR_DGRAD_EPI": "gather", "LFSR_DGRAD_ANG": "gather", "LFSR_WGRAD_PW": "gather", "LFSR_NO_ROWGEMM": "1"})
+    for k in ("LFSR_WGRAD3", "LFSR_WGRAD_EPI", "LFSR_DGRAD_EPI", "LFSR_DGRAD_ANG", "LFSR_WGRAD_PW", "LFSR_NO_ROWGEMM"):
         monkeypatch.delenv(k, raising=False)
     worst = 0.0
     for k in new:
