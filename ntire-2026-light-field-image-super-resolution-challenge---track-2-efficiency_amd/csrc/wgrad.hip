@@ -278,20 +278,40 @@ __device__ __forceinline__ void wgrad_wino_body(const Wgrad3Args& p, float* smw,
     }
     __syncthreads();   // (the only barrier of a tile: the other buffer was last read before the previous tile's barrier)
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);     // next tile flies under this tile's MFMAs
-#pragma unroll W2_UNROLL
-    for (int s = 0; s < 4; ++s) {
+    // K steps software-pipelined: the raw LDS reads of step s + 1 are issued before the MFMAs of step s (their latency runs under ~1000 MFMA cycles)
+    float rawg[2][2][4], rawa[2][4][4], rawb[2][4][4];
+    auto load_raw = [&](int s, int buf) {
       const int cx = 2 * (4 * s + g);           // first pixel column of this lane's Winograd tile (= its first halo column)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float* gp = sG + cx * W2ROW + (2 * nh + nb) * 16 + l15;
+        if (TA == 0) { rawg[buf][nb][0] = gp[0]; rawg[buf][nb][1] = gp[W2ROW]; }
+        else if (TA == 3) { rawg[buf][nb][0] = gp[32 * W2ROW]; rawg[buf][nb][1] = gp[33 * W2ROW]; }
+        else { rawg[buf][nb][0] = gp[0]; rawg[buf][nb][1] = gp[W2ROW]; rawg[buf][nb][2] = gp[32 * W2ROW]; rawg[buf][nb][3] = gp[33 * W2ROW]; }
+      }
+      constexpr int RA = TA == 0 ? 0 : 1, RB = TA == 0 ? 2 : TA == 3 ? 3 : 2;   // the two patch rows transform row a combines
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const float* xa = sX + (RA * 34 + cx) * W2ROW + kb * 16 + l15;
+        const float* xb = sX + (RB * 34 + cx) * W2ROW + kb * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { rawa[buf][kb][j] = xa[j * W2ROW]; rawb[buf][kb][j] = xb[j * W2ROW]; }
+      }
+    };
+    load_raw(0, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int buf = s & 1;
       // A operands: dY'[a][b] of channels n = (2 nh + nb) 16 + l15
       float av[2][4];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        const float* gp = sG + cx * W2ROW + (2 * nh + nb) * 16 + l15;
         float r0, r1;
-        if (TA == 0) { r0 = gp[0]; r1 = gp[W2ROW]; }
-        else if (TA == 3) { r0 = -gp[32 * W2ROW]; r1 = -gp[33 * W2ROW]; }
+        if (TA == 0) { r0 = rawg[buf][nb][0]; r1 = rawg[buf][nb][1]; }
+        else if (TA == 3) { r0 = -rawg[buf][nb][0]; r1 = -rawg[buf][nb][1]; }
         else {
-          const float a0 = gp[0], a1 = gp[W2ROW], b0 = gp[32 * W2ROW], b1 = gp[33 * W2ROW];
-          r0 = TA == 1 ? a0 + b0 : a0 - b0; r1 = TA == 1 ? a1 + b1 : a1 - b1;
+          r0 = TA == 1 ? rawg[buf][nb][0] + rawg[buf][nb][2] : rawg[buf][nb][0] - rawg[buf][nb][2];
+          r1 = TA == 1 ? rawg[buf][nb][1] + rawg[buf][nb][3] : rawg[buf][nb][1] - rawg[buf][nb][3];
         }
         av[nb][0] = r0; av[nb][1] = r0 + r1; av[nb][2] = r0 - r1; av[nb][3] = -r1;
       }
@@ -299,17 +319,16 @@ __device__ __forceinline__ void wgrad_wino_body(const Wgrad3Args& p, float* smw,
       float bv[4][4];
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        constexpr int RA = TA == 0 ? 0 : TA == 3 ? 1 : 1, RB = TA == 0 ? 2 : TA == 3 ? 3 : 2;   // the two patch rows transform row a combines
-        const float* xa = sX + (RA * 34 + cx) * W2ROW + kb * 16 + l15;
-        const float* xb = sX + (RB * 34 + cx) * W2ROW + kb * 16 + l15;
         float t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float u = xa[j * W2ROW], v = xb[j * W2ROW];
+          const float u = rawa[buf][kb][j], v = rawb[buf][kb][j];
           t[j] = TA == 0 ? u - v : TA == 1 ? u + v : TA == 2 ? v - u : u - v;   // a = 0: d0 - d2; 1: d1 + d2; 2: d2 - d1; 3: d1 - d3
         }
         bv[kb][0] = t[0] - t[2]; bv[kb][1] = t[1] + t[2]; bv[kb][2] = t[2] - t[1]; bv[kb][3] = t[1] - t[3];
       }
+      if (s < 3) load_raw(s + 1, buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);        // (keeps the next step's reads in front of this step's MFMAs)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
