@@ -238,6 +238,18 @@ int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const fl
 int lfsr_ffn_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
                  const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
                  long long M, int K1, int H, int N2, float slope, void* stream);
+/* The same block with its leading LayerNorm (feed_forward.0: EPIT.py:85, LFT.py:152,217) formed in registers:
+ *   y = res + W2 . act(W1 . LayerNorm(x))      x: (M, K1) RAW tokens, gamma / beta (K1), eps as nn.LayerNorm */
+int lfsr_ffn_ln_fwd(const float* x, int x_stride, int x_choff, const float* gamma, const float* beta, float eps,
+                    const float* w1_packed, const float* w2_packed, const float* res, int res_stride, int res_choff,
+                    float* y, int y_stride, int y_choff, long long M, int K1, int H, int N2, float slope, void* stream);
+/* LayerNorm + attention in-projection in one launch (EPIT.py:113-121; LFT.py:190-197,236-241): weight rows n < ln_cols (q | k) see
+ * LayerNorm(x [+ pe[(row / pe_div) % pe_rows]]), rows n >= ln_cols (v) see x; columns n >= split_n go to y2 (column n - split_n).
+ * K in {64,128}; N, ln_cols, split_n multiples of 64.  Same bits as lfsr_layernorm_fwd + lfsr_linear_fwd. */
+int lfsr_linear_ln_fwd(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* gamma, const float* beta,
+                       float eps, int ln_cols, const float* pe, int pe_stride, int pe_rows, int pe_div,
+                       float* y, int y_stride, int y_choff, float* y2, int y2_stride, int y2_choff, int split_n,
+                       long long M, int N, void* stream);
 /* nn.MultiheadAttention core with the reference's additive window mask evaluated as a predicate (EPIT.py:93-122,
  * LFT.py:161-199,238-241): o = softmax(q k^T / sqrt(hd) + mask) v per head; hd in {8,16}.
  * Sequences (s0,s1,s2) start at pixel s0*bs0+s1*bs1+s2*bs2; token (t1,t2) sits at + t1*st1 + t2*st2; token (t1,t2)

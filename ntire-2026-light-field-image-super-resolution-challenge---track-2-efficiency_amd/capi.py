@@ -79,6 +79,8 @@ SIGNATURES = {
     "lfsr_linear_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, C.c_longlong, c_i, c_f, c_p]),
     "lfsr_ycbcr2rgb_views": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, C.POINTER(C.c_double), C.POINTER(C.c_double), c_p]),
     "lfsr_ffn_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, C.c_longlong, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_ffn_ln_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_i, C.c_longlong, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_linear_ln_fwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_f, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_i, C.c_longlong, c_i, c_p]),
     "lfsr_window_attn_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                                    C.c_longlong, C.c_longlong, C.c_longlong, c_i, c_i, C.c_longlong, C.c_longlong, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_upsample_ps_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -92,14 +92,26 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
   auto conv = [&](const float* in, const std::string& key, float* o, const float* r1, const float* r2, float slope) -> int {
     return lfsr_conv3x3_fwd(in, 64, 0, P.w(key), o, 64, 0, r1, 64, 0, r2, 64, 0, nimg, h, w, slope, stream);
   };
+  const char* lf = getenv("LFSR_LN_FUSE");
+  // LayerNorms formed inside the consuming kernel: feed_forward.0 in the fused feed-forward (default: 293 us against 33 + 295 us, 10 launches less per forward);
+  // the attention norm inside the q | k | v projection only with LFSR_LN_FUSE=2 -- measured SLOWER (334 us against 33 + 209 us: each of the four q | k column
+  // panels repeats the norm of its row tile, and 384 x 128 fp32 weights do not fit one block's LDS); LFSR_LN_FUSE=0: every norm as its own launch
+  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf && lf[0] == '2', no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;
   // BasicTrans.forward (EPIT.py:110-128) over all sequences of one pass
   auto trans = [&](const float* X, const std::string& e, int vertical, float* Yo) -> int {
     int r;
     if ((r = lfsr_linear_fwd(X, 64, 0, 64, P.w(e + "linear_in.weight"), nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 1.0f, stream))) return r;
-    if ((r = lfsr_layernorm_fwd(T, 128, 0, nullptr, 0, 0, 1, P.w(e + "norm.weight"), P.w(e + "norm.bias"), TN, 128, 0, npix, 128, 1e-5f, stream))) return r;
     const float* Win = P.w(e + "attention.in_proj_weight");
-    if ((r = lfsr_linear_fwd(TN, 128, 0, 128, Win, nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 1.0f, stream))) return r;              // q | k from LN(t)
-    if ((r = lfsr_linear_fwd(T, 128, 0, 128, Win + 256 * 128, nullptr, nullptr, 0, 0, V, 128, 0, npix, 128, 1.0f, stream))) return r;    // v from t
+    // q | k from LayerNorm(t), v from t (LFSR_LN_FUSE=2: one launch, the norm formed on the staged rows)
+    r = ln_fuse_qkv ? lfsr_rowgemm_ln_launch(T, 128, 0, 128, Win, P.w(e + "norm.weight"), P.w(e + "norm.bias"), 1e-5f, 256, nullptr, 0, 1, 1, QK, 256, 0, V, 128, 0, 256,
+                                         npix, 384, lfsr_stream(stream))
+                : LFSR_E_ARG;
+    if (r == LFSR_E_ARG) {
+      if ((r = lfsr_layernorm_fwd(T, 128, 0, nullptr, 0, 0, 1, P.w(e + "norm.weight"), P.w(e + "norm.bias"), TN, 128, 0, npix, 128, 1e-5f, stream))) return r;
+      if ((r = lfsr_linear_fwd(TN, 128, 0, 128, Win, nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 1.0f, stream))) return r;              // q | k from LN(t)
+      r = lfsr_linear_fwd(T, 128, 0, 128, Win + 256 * 128, nullptr, nullptr, 0, 0, V, 128, 0, npix, 128, 1.0f, stream);                  // v from t
+    }
+    if (r) return r;
     // mask_field = [2A, 11] (EPIT.py:147): all angular positions, spatial window [j-5, j+6)
     if (!vertical) r = lfsr_window_attn_fwd(QK, 256, 0, QK, 256, 128, V, 128, 0, TN, 128, 0, 8, 16, B, A, w, (long long)AA * HW, HW, 1,
                                             A, h, (long long)A * HW, w, A, A, 5, 6, 0, stream);      // sequence (b, v, x); tokens (u, y)
@@ -107,13 +119,20 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
                                   A, w, HW, 1, A, A, 5, 6, 0, stream);                               // sequence (b, u, y); tokens (v, x)
     if (r) return r;
     if ((r = lfsr_linear_fwd(TN, 128, 0, 128, P.w(e + "attention.out_proj.weight"), nullptr, T, 128, 0, T2, 128, 0, npix, 128, 1.0f, stream))) return r;
-    if ((r = lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, P.w(e + "feed_forward.0.weight"), P.w(e + "feed_forward.0.bias"), V, 128, 0, npix, 128, 1e-5f, stream))) return r;
-    if (getenv("LFSR_NO_FFN_FUSED")) {   // two-launch form (A/B runs): the hidden activations go through HBM
-      if ((r = lfsr_linear_fwd(V, 128, 0, 128, P.w(e + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream))) return r;   // ReLU
-      if ((r = lfsr_linear_fwd(QK, 256, 0, 256, P.w(e + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream))) return r;
-    } else if ((r = lfsr_ffn_fwd(V, 128, 0, P.w(e + "feed_forward.1.weight"), P.w(e + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0, npix, 128, 256, 128, 0.0f, stream))) {
-      return r;
+    const float *fg = P.w(e + "feed_forward.0.weight"), *fb = P.w(e + "feed_forward.0.bias");
+    r = (ln_fuse && !no_ffn_fused) ? lfsr_ffn_ln_launch(T2, 128, 0, fg, fb, 1e-5f, P.w(e + "feed_forward.1.weight"), P.w(e + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0,
+                                                        npix, 128, 256, 128, 0.0f, lfsr_stream(stream))
+                                   : LFSR_E_ARG;
+    if (r == LFSR_E_ARG) {
+      if ((r = lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, fg, fb, V, 128, 0, npix, 128, 1e-5f, stream))) return r;
+      if (no_ffn_fused) {   // two-launch form (A/B runs): the hidden activations go through HBM
+        if ((r = lfsr_linear_fwd(V, 128, 0, 128, P.w(e + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream))) return r;   // ReLU
+        r = lfsr_linear_fwd(QK, 256, 0, 256, P.w(e + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream);
+      } else {
+        r = lfsr_ffn_fwd(V, 128, 0, P.w(e + "feed_forward.1.weight"), P.w(e + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0, npix, 128, 256, 128, 0.0f, stream);
+      }
     }
+    if (r) return r;
     return lfsr_linear_fwd(T, 128, 0, 128, P.w(e + "linear_out.weight"), nullptr, nullptr, 0, 0, Yo, 64, 0, npix, 64, 1.0f, stream);
   };
 

@@ -27,6 +27,7 @@ struct FfnArgs {
   long long M; int H;
   int y_bytes, r_bytes;                         // true byte spans (descriptor extents; 0 = absent)
   float slope;                                  // hidden activation: 0 = ReLU
+  const float* ln_g; const float* ln_b; float ln_eps;   // non-null: X holds the RAW tokens and xn = LayerNorm(X) is formed in registers (feed_forward.0)
 };
 
 template <int K1, int N2>
@@ -101,6 +102,30 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs p) {
       // would wait for every younger load too -- i.e. for the weight prefetch of the next chunk -- inside each chunk's GEMM 1
 #pragma unroll
       for (int j = 0; j < KJ; ++j) asm volatile("" :: "v"(xa[j].x), "v"(xa[j].y), "v"(xa[j].z), "v"(xa[j].w));
+      if (p.ln_g) {
+        // a token row lives in lanes l31 and l31 + 32 (alternating groups of four channels): two-pass LayerNorm with one cross-half exchange per pass
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) sm += (xa[j].x + xa[j].y) + (xa[j].z + xa[j].w);
+        sm += __shfl_xor(sm, 32);
+        const float mu = sm * (1.0f / K1);
+        float q2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+          xa[j].x -= mu; xa[j].y -= mu; xa[j].z -= mu; xa[j].w -= mu;
+          q2 += (xa[j].x * xa[j].x + xa[j].y * xa[j].y) + (xa[j].z * xa[j].z + xa[j].w * xa[j].w);
+        }
+        q2 += __shfl_xor(q2, 32);
+        const float rstd = 1.0f / sqrtf(q2 * (1.0f / K1) + p.ln_eps);
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+          const float4 gv = *reinterpret_cast<const float4*>(p.ln_g + 8 * j + 4 * half);
+          const float4 bv = *reinterpret_cast<const float4*>(p.ln_b + 8 * j + 4 * half);
+          xa[j] = make_float4(xa[j].x * rstd * gv.x + bv.x, xa[j].y * rstd * gv.y + bv.y, xa[j].z * rstd * gv.z + bv.z, xa[j].w * rstd * gv.w + bv.w);
+        }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) asm volatile("" :: "v"(xa[j].x), "v"(xa[j].y), "v"(xa[j].z), "v"(xa[j].w));
+      }
     }
 #pragma unroll
     for (int t = 0; t < NT2; ++t)
@@ -208,19 +233,35 @@ int launch_ffn(const FfnArgs& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int lfsr_ffn_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
-                            const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
-                            long long M, int K1, int H, int N2, float slope, void* stream) {
+// y = res + W2 . act(W1 . LayerNorm(x)) when ln_g / ln_b are given (x the raw tokens), else the plain form
+int lfsr_ffn_ln_launch(const float* x, int x_stride, int x_choff, const float* ln_g, const float* ln_b, float ln_eps, const float* w1_packed, const float* w2_packed,
+                       const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
+                       long long M, int K1, int H, int N2, float slope, hipStream_t st) {
   if (!x || !w1_packed || !w2_packed || !y || M <= 0 || H <= 0 || H % 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if (x_stride < x_choff + K1 || y_stride < y_choff + N2 || (res && res_stride < res_choff + N2)) return LFSR_E_ARG;
   if (M * (long long)(y_stride > res_stride ? y_stride : res_stride) * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets in the epilogue
   FfnArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.W1 = w1_packed; p.W2 = w2_packed;
   p.R = res; p.r_stride = res_stride; p.r_choff = res_choff; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
-  p.M = M; p.H = H; p.slope = slope;
+  p.M = M; p.H = H; p.slope = slope; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps;
   p.y_bytes = (int)(M * y_stride * 4); p.r_bytes = res ? (int)(M * res_stride * 4) : 0;
-  hipStream_t st = lfsr_stream(stream);
+  if ((ln_g != nullptr) != (ln_b != nullptr) || (((uintptr_t)ln_g | (uintptr_t)ln_b) & 15)) return LFSR_E_ARG;
   if (K1 == 128 && N2 == 128) return launch_ffn<128, 128>(p, st);
   if (K1 == 64 && N2 == 64) return launch_ffn<64, 64>(p, st);
   return LFSR_E_ARG;
+}
+
+extern "C" int lfsr_ffn_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
+                            const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
+                            long long M, int K1, int H, int N2, float slope, void* stream) {
+  return lfsr_ffn_ln_launch(x, x_stride, x_choff, nullptr, nullptr, 0.f, w1_packed, w2_packed, res, res_stride, res_choff, y, y_stride, y_choff, M, K1, H, N2, slope,
+                            lfsr_stream(stream));
+}
+
+extern "C" int lfsr_ffn_ln_fwd(const float* x, int x_stride, int x_choff, const float* gamma, const float* beta, float eps,
+                               const float* w1_packed, const float* w2_packed, const float* res, int res_stride, int res_choff,
+                               float* y, int y_stride, int y_choff, long long M, int K1, int H, int N2, float slope, void* stream) {
+  if (!gamma || !beta) return LFSR_E_ARG;
+  return lfsr_ffn_ln_launch(x, x_stride, x_choff, gamma, beta, eps, w1_packed, w2_packed, res, res_stride, res_choff, y, y_stride, y_choff, M, K1, H, N2, slope,
+                            lfsr_stream(stream));
 }

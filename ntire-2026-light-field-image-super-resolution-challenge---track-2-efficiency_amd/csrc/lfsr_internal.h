@@ -111,8 +111,16 @@ int lfsr_pack_weight_chunkT(const float* w, float* out, int O, int C, int ch, in
 // rowgemm.hip: persistent row-streaming GEMM with LDS-resident weights; LFSR_E_ARG = shape not covered (use the gather-GEMM)
 int lfsr_rowgemm_dgrad144_launch(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, const float* mk, int mk_stride, int mk_choff, float mk_slope,
                                  float* dx, int dx_stride, int dx_choff, long long M, hipStream_t st);
+int lfsr_rowgemm_ln_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* ln_g, const float* ln_b, float ln_eps, int ln_cols,
+                           const float* pe, int pe_stride, int pe_rows, int pe_div, float* y, int y_stride, int y_choff,
+                           float* y2, int y2_stride, int y2_choff, int split_n, long long M, int N, hipStream_t st);
 int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
                         const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st);
+
+// ffn_fused.hip: feed-forward block with the LayerNorm in front of it formed in registers (ln_g / ln_b null: x is already normalised)
+int lfsr_ffn_ln_launch(const float* x, int x_stride, int x_choff, const float* ln_g, const float* ln_b, float ln_eps, const float* w1_packed, const float* w2_packed,
+                       const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
+                       long long M, int K1, int H, int N2, float slope, hipStream_t st);
 
 // attn_mfma.hip: EPI attention on MFMA; LFSR_E_ARG = geometry not covered
 int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,

@@ -119,44 +119,71 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
   RC(lfsr_lft_position_fwd(SPOS, APE, A, h, w, 64, stream));              // LFT.py:84-85
   const float* cur = BUF0;
   const bool no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;   // two-launch feed-forward (A/B runs)
+  const char* lf = getenv("LFSR_LN_FUSE");
+  // LayerNorms formed inside the consuming kernel (see epit.cpp): feed_forward.0 inside the fused feed-forward by default; the attention norms inside the
+  // q | k | v projection only with LFSR_LN_FUSE=2 (measured slower: 1464 against 143 + 795 us for SpaTrans at 32 patches); LFSR_LN_FUSE=0: all norms as launches
+  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf && lf[0] == '2';
   for (int b = 0; b < c->nlayer; ++b) {
     // ---- AngTrans (LFT.py:233-246): tokens = the A*A views at one (y, x); E = 64, 8 heads of 8, no mask -----------
     std::string an = "altblock." + std::to_string(b) + ".ang_trans.";
     float* a_out = (cur == Pb) ? Qb : Pb;
-    RC(lfsr_layernorm_fwd(cur, 64, 0, APE, 64, AA, HW, P.w(an + "norm.weight"), P.w(an + "norm.bias"), N64, 64, 0, npix, 64, 1e-5f, stream));
     const float* Wa = P.w(an + "attention.in_proj_weight");
-    RC(lfsr_linear_fwd(N64, 64, 0, 64, Wa, nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 1.0f, stream));                 // q | k
-    RC(lfsr_linear_fwd(cur, 64, 0, 64, Wa + 128 * 64, nullptr, nullptr, 0, 0, C1, 64, 0, npix, 64, 1.0f, stream));        // v from the raw token
+    // q | k from LayerNorm(token + PE), v from the raw token (LFSR_LN_FUSE=2: one launch)
+    rc = ln_fuse_qkv ? lfsr_rowgemm_ln_launch(cur, 64, 0, 64, Wa, P.w(an + "norm.weight"), P.w(an + "norm.bias"), 1e-5f, 128, APE, 64, AA, HW, T, 128, 0, C1, 64, 0, 128,
+                                          npix, 192, lfsr_stream(stream))
+                 : LFSR_E_ARG;
+    if (rc == LFSR_E_ARG) {
+      RC(lfsr_layernorm_fwd(cur, 64, 0, APE, 64, AA, HW, P.w(an + "norm.weight"), P.w(an + "norm.bias"), N64, 64, 0, npix, 64, 1e-5f, stream));
+      RC(lfsr_linear_fwd(N64, 64, 0, 64, Wa, nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 1.0f, stream));                 // q | k
+      RC(lfsr_linear_fwd(cur, 64, 0, 64, Wa + 128 * 64, nullptr, nullptr, 0, 0, C1, 64, 0, npix, 64, 1.0f, stream));        // v from the raw token
+    } else if (rc) return rc;
     RC(lfsr_window_attn_fwd(T, 128, 0, T, 128, 64, C1, 64, 0, C2, 64, 0, 8, 8, B, h, w, (long long)AA * HW, w, 1,
                             AA, 1, HW, 0, AA, AA, 0, 1, 0, stream));
     RC(lfsr_linear_fwd(C2, 64, 0, 64, P.w(an + "attention.out_proj.weight"), nullptr, cur, 64, 0, C1, 64, 0, npix, 64, 1.0f, stream));     // + token
-    RC(lfsr_layernorm_fwd(C1, 64, 0, nullptr, 0, 0, 1, P.w(an + "feed_forward.0.weight"), P.w(an + "feed_forward.0.bias"), N64, 64, 0, npix, 64, 1e-5f, stream));
-    if (no_ffn_fused) {
-      RC(lfsr_linear_fwd(N64, 64, 0, 64, P.w(an + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 0.0f, stream));     // ReLU
-      RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(an + "feed_forward.4.weight"), nullptr, C1, 64, 0, a_out, 64, 0, npix, 64, 1.0f, stream));
-    } else {
-      RC(lfsr_ffn_fwd(N64, 64, 0, P.w(an + "feed_forward.1.weight"), P.w(an + "feed_forward.4.weight"), C1, 64, 0, a_out, 64, 0, npix, 64, 128, 64, 0.0f, stream));
-    }
+    const float *afg = P.w(an + "feed_forward.0.weight"), *afb = P.w(an + "feed_forward.0.bias");
+    rc = (ln_fuse && !no_ffn_fused) ? lfsr_ffn_ln_launch(C1, 64, 0, afg, afb, 1e-5f, P.w(an + "feed_forward.1.weight"), P.w(an + "feed_forward.4.weight"), C1, 64, 0,
+                                                         a_out, 64, 0, npix, 64, 128, 64, 0.0f, lfsr_stream(stream))
+                                    : LFSR_E_ARG;
+    if (rc == LFSR_E_ARG) {
+      RC(lfsr_layernorm_fwd(C1, 64, 0, nullptr, 0, 0, 1, afg, afb, N64, 64, 0, npix, 64, 1e-5f, stream));
+      if (no_ffn_fused) {
+        RC(lfsr_linear_fwd(N64, 64, 0, 64, P.w(an + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 0.0f, stream));     // ReLU
+        RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(an + "feed_forward.4.weight"), nullptr, C1, 64, 0, a_out, 64, 0, npix, 64, 1.0f, stream));
+      } else {
+        RC(lfsr_ffn_fwd(N64, 64, 0, P.w(an + "feed_forward.1.weight"), P.w(an + "feed_forward.4.weight"), C1, 64, 0, a_out, 64, 0, npix, 64, 128, 64, 0.0f, stream));
+      }
+    } else if (rc) return rc;
     // ---- SpaTrans (LFT.py:188-203): tokens = the h*w positions of one view; E = 128, 8 heads of 16, 5x5 window --------
     std::string sp = "altblock." + std::to_string(b) + ".spa_trans.";
     float* s_out = (a_out == Pb) ? Qb : Pb;
     RC(lfsr_conv3x3_fwd(a_out, 64, 0, P.w(sp + "MLP.weight#lo"), T, 128, 0, nullptr, 0, 0, nullptr, 0, 0, nimg, h, w, 1.0f, stream));   // unfold + MLP (tokens),
     RC(lfsr_conv3x3_fwd(a_out, 64, 0, P.w(sp + "MLP.weight#hi"), T, 128, 64, nullptr, 0, 0, nullptr, 0, 0, nimg, h, w, 1.0f, stream));  // as two 64-output convs
     RC(lfsr_conv3x3_n_fwd(SPOS, 64, 0, P.w(sp + "MLP.weight"), SPE, 128, 0, 1, h, w, 128, 1.0f, stream));              // same embedding of the PE map
-    RC(lfsr_layernorm_fwd(T, 128, 0, SPE, 128, HW, 1, P.w(sp + "norm.weight"), P.w(sp + "norm.bias"), TN, 128, 0, npix, 128, 1e-5f, stream));
     const float* Ws = P.w(sp + "attention.in_proj_weight");
-    RC(lfsr_linear_fwd(TN, 128, 0, 128, Ws, nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 1.0f, stream));
-    RC(lfsr_linear_fwd(T, 128, 0, 128, Ws + 256 * 128, nullptr, nullptr, 0, 0, V, 128, 0, npix, 128, 1.0f, stream));
+    rc = ln_fuse_qkv ? lfsr_rowgemm_ln_launch(T, 128, 0, 128, Ws, P.w(sp + "norm.weight"), P.w(sp + "norm.bias"), 1e-5f, 256, SPE, 128, HW, 1, QK, 256, 0, V, 128, 0, 256,
+                                          npix, 384, lfsr_stream(stream))
+                 : LFSR_E_ARG;
+    if (rc == LFSR_E_ARG) {
+      RC(lfsr_layernorm_fwd(T, 128, 0, SPE, 128, HW, 1, P.w(sp + "norm.weight"), P.w(sp + "norm.bias"), TN, 128, 0, npix, 128, 1e-5f, stream));
+      RC(lfsr_linear_fwd(TN, 128, 0, 128, Ws, nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 1.0f, stream));
+      RC(lfsr_linear_fwd(T, 128, 0, 128, Ws + 256 * 128, nullptr, nullptr, 0, 0, V, 128, 0, npix, 128, 1.0f, stream));
+    } else if (rc) return rc;
     // window [i-2, i+3) x [j-2, min(h, j+3)): the column clamp uses h (LFT.py:168)
     RC(lfsr_window_attn_fwd(QK, 256, 0, QK, 256, 128, V, 128, 0, TN, 128, 0, 8, 16, nimg, 1, 1, HW, 0, 0, h, w, w, 1, 2, 3, 2, 3, h, stream));
     RC(lfsr_linear_fwd(TN, 128, 0, 128, P.w(sp + "attention.out_proj.weight"), nullptr, T, 128, 0, T2, 128, 0, npix, 128, 1.0f, stream));
-    RC(lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, P.w(sp + "feed_forward.0.weight"), P.w(sp + "feed_forward.0.bias"), V, 128, 0, npix, 128, 1e-5f, stream));
-    if (no_ffn_fused) {
-      RC(lfsr_linear_fwd(V, 128, 0, 128, P.w(sp + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream));
-      RC(lfsr_linear_fwd(QK, 256, 0, 256, P.w(sp + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream));
-    } else {
-      RC(lfsr_ffn_fwd(V, 128, 0, P.w(sp + "feed_forward.1.weight"), P.w(sp + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0, npix, 128, 256, 128, 0.0f, stream));
-    }
+    const float *sfg = P.w(sp + "feed_forward.0.weight"), *sfb = P.w(sp + "feed_forward.0.bias");
+    rc = (ln_fuse && !no_ffn_fused) ? lfsr_ffn_ln_launch(T2, 128, 0, sfg, sfb, 1e-5f, P.w(sp + "feed_forward.1.weight"), P.w(sp + "feed_forward.4.weight"), T2, 128, 0,
+                                                         T, 128, 0, npix, 128, 256, 128, 0.0f, lfsr_stream(stream))
+                                    : LFSR_E_ARG;
+    if (rc == LFSR_E_ARG) {
+      RC(lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, sfg, sfb, V, 128, 0, npix, 128, 1e-5f, stream));
+      if (no_ffn_fused) {
+        RC(lfsr_linear_fwd(V, 128, 0, 128, P.w(sp + "feed_forward.1.weight"), nullptr, nullptr, 0, 0, QK, 256, 0, npix, 256, 0.0f, stream));
+        RC(lfsr_linear_fwd(QK, 256, 0, 256, P.w(sp + "feed_forward.4.weight"), nullptr, T2, 128, 0, T, 128, 0, npix, 128, 1.0f, stream));
+      } else {
+        RC(lfsr_ffn_fwd(V, 128, 0, P.w(sp + "feed_forward.1.weight"), P.w(sp + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0, npix, 128, 256, 128, 0.0f, stream));
+      }
+    } else if (rc) return rc;
     // Conv3d 1x1x1 128 -> 64 (LFT.py:183-186); the network-level skip (LFT.py:91) rides on the last layer's projection
     const bool last = b == c->nlayer - 1;
     RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(sp + "linear.0.weight"), nullptr, last ? BUF0 : nullptr, 64, 0, s_out, 64, 0, npix, 64, 1.0f, stream));

@@ -22,9 +22,14 @@ struct RowGemmArgs {
   float* Y; int y_stride; int y_choff;
   long long M; int N;
   float slope;
+  // LN form: the rows feeding the panels n0 < ln_cols are LayerNorm(x (+ pe)) (nn.LayerNorm(K), eps ln_eps); the others see the raw rows
+  const float* ln_g; const float* ln_b; float ln_eps; int ln_cols;
+  const float* pe; int pe_stride; int pe_rows; int pe_div;        // pe row of token m: (m / pe_div) % pe_rows
+  // second output: the panels n0 >= split_n store to Y2 (column n - split_n)
+  float* Y2; int y2_stride; int y2_choff; int split_n;
 };
 
-template <int K, int NB, int BMR>
+template <int K, int NB, int BMR, bool LN = false>
 __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
   constexpr int LR = K + 4;                 // LDS row stride (floats)
   constexpr int NTH = BMR * 4;              // BMR/32 row groups x 2 column halves x 64 lanes
@@ -72,12 +77,29 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
     offX[i] = idx < BMR * CPR ? (r * p.x_stride + p.x_choff + c * 4) * 4 : (int)0x80000000u;
   }
   float4 ra[AL];
+  // LN form: a row is spread over CPR consecutive lanes, one 16-B chunk each (chunk tid % CPR of the rows tid / CPR + i NTH / CPR) -- the layout and the
+  // reduction order of k_layernorm, so the fused form returns the same bits as LayerNorm launch + plain row-GEMM
+  static_assert(!LN || (NTH % CPR == 0 && (BMR * CPR) % NTH == 0 && (CPR & (CPR - 1)) == 0 && CPR <= 64), "LN form: whole rows per lane group");
+  const bool do_ln = LN && n0 < p.ln_cols;
+  float4 lng = make_float4(0.f, 0.f, 0.f, 0.f), lnb = lng;
+  float4 rp[LN ? AL : 1];
+  if (do_ln) {
+    lng = *reinterpret_cast<const float4*>(p.ln_g + (tid % CPR) * 4);
+    lnb = *reinterpret_cast<const float4*>(p.ln_b + (tid % CPR) * 4);
+  }
   auto prefetch = [&](long long tile) {
     const int s4 = (int)(tile * BMR) * p.x_stride * 4;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offX[i], s4, 0));
       ra[i] = make_float4(v.x, v.y, v.z, v.w);
+    }
+    if constexpr (LN) if (do_ln && p.pe) {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        const int m = (int)(tile * BMR) + tid / CPR + i * (NTH / CPR);
+        rp[i] = *reinterpret_cast<const float4*>(p.pe + (long long)((m / p.pe_div) % p.pe_rows) * p.pe_stride + (tid % CPR) * 4);
+      }
     }
   };
 
@@ -86,6 +108,23 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
   const float* aRow = sA + (rg * 32 + l31) * LR + 4 * half;
   const float* bRow = sW + (ng * (NB / 2) + l31) * LR + 4 * half;
   for (; tile < ntiles; tile += gridDim.x) {
+    if constexpr (LN) if (do_ln) {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) {
+        float4 v = ra[i];
+        if (p.pe) { v.x += rp[i].x; v.y += rp[i].y; v.z += rp[i].z; v.w += rp[i].w; }
+        float sm = v.x + v.y + v.z + v.w;
+#pragma unroll
+        for (int o = CPR / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o, CPR);
+        const float mu = sm * (1.0f / K);
+        const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+        float q2 = dx * dx + dy * dy + dz * dz + dw * dw;
+#pragma unroll
+        for (int o = CPR / 2; o > 0; o >>= 1) q2 += __shfl_xor(q2, o, CPR);
+        const float rstd = 1.0f / sqrtf(q2 * (1.0f / K) + p.ln_eps);
+        ra[i] = make_float4(dx * rstd * lng.x + lnb.x, dy * rstd * lng.y + lnb.y, dz * rstd * lng.z + lnb.z, dw * rstd * lng.w + lnb.w);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       int idx = tid + NTH * i;
@@ -127,6 +166,9 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
     // epilogue straight from the accumulators: register group q of tile t = channels n0' + 32 t + 8 q + 4 half .. + 3 of row m0 + 32 rg + l31:
     // one 16-B store per group (bias / residual as 16-B loads, all of a tile's residual loads issued before the first use)
     const long long m = tile * BMR + rg * 32 + l31;
+    const bool second = p.Y2 && n0 >= p.split_n;        // (block-uniform)
+    float* const Yp = second ? p.Y2 : p.Y;
+    const int ys = second ? p.y2_stride : p.y_stride, yc = second ? p.y2_choff - p.split_n : p.y_choff;
     if (m < p.M) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -153,14 +195,14 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
               const float4 mk = mkv[t][q];
               v[0] *= mk.x > 0.f ? 1.f : p.mk_slope; v[1] *= mk.y > 0.f ? 1.f : p.mk_slope; v[2] *= mk.z > 0.f ? 1.f : p.mk_slope; v[3] *= mk.w > 0.f ? 1.f : p.mk_slope;
             }
-            *reinterpret_cast<float4*>(p.Y + m * p.y_stride + p.y_choff + n) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(Yp + m * ys + yc + n) = make_float4(v[0], v[1], v[2], v[3]);
           } else {   // ragged N (not a multiple of 4): element by element
             for (int k = 0; k < 4 && n + k < p.N; ++k) {
               float x = v[k] + (p.bias ? p.bias[n + k] : 0.f);
               x = x >= 0.f ? x : x * p.slope;
               if (p.R1) x += p.R1[m * p.r1_stride + p.r1_choff + n + k];
               if (p.Mk) x *= p.Mk[m * p.mk_stride + p.mk_choff + n + k] > 0.f ? 1.f : p.mk_slope;
-              p.Y[m * p.y_stride + p.y_choff + n + k] = x;
+              Yp[m * ys + yc + n + k] = x;
             }
           }
         }
@@ -170,7 +212,7 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
   }
 }
 
-template <int K, int NB, int BMR>
+template <int K, int NB, int BMR, bool LN = false>
 int launch_rowgemm(const RowGemmArgs& p, hipStream_t st) {
   constexpr int smem = (NB + BMR) * (K + 4) * 4;
   constexpr int per_cu = smem <= 78 * 1024 ? 2 : 1;
@@ -178,16 +220,17 @@ int launch_rowgemm(const RowGemmArgs& p, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<K, NB, BMR>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm<K, NB, BMR, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
   const long long ntiles = (p.M + BMR - 1) / BMR;
   const int nby = (p.N + NB - 1) / NB;
   int gx = 256 * per_cu / nby;              // fill every CU with the blocks its LDS admits
+  if (gx > 8) gx &= ~7;                     // a multiple of 8: the nby panel blocks of a row tile land on one XCD (block id = x + gx y) and share its L2
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = (int)ntiles;
-  hipLaunchKernelGGL((k_rowgemm<K, NB, BMR>), dim3((unsigned)gx, (unsigned)nby), dim3(BMR * 4), smem, st, p);
+  hipLaunchKernelGGL((k_rowgemm<K, NB, BMR, LN>), dim3((unsigned)gx, (unsigned)nby), dim3(BMR * 4), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
@@ -206,6 +249,27 @@ int lfsr_rowgemm_dgrad144_launch(const float* dy, int dy_stride, int dy_choff, c
   p.X = dy; p.x_stride = dy_stride; p.x_choff = dy_choff; p.Wp = wT_packed; p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
   p.Y = dx; p.y_stride = dx_stride; p.y_choff = dx_choff; p.M = M; p.N = 144; p.slope = 1.0f;
   return launch_rowgemm<64, 192, 64>(p, st);
+}
+
+// LayerNorm + projections in one launch (BasicTrans.forward, EPIT.py:113-121; SpaTrans / AngTrans, LFT.py:190-197 / :236-241): the weight rows n < ln_cols
+// (q | k) see LayerNorm(x (+ pe)), the rows n >= ln_cols (v) see x itself; columns n >= split_n go to y2.  K = 64 or 128, N and split_n multiples of 64.
+int lfsr_rowgemm_ln_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* ln_g, const float* ln_b, float ln_eps, int ln_cols,
+                           const float* pe, int pe_stride, int pe_rows, int pe_div, float* y, int y_stride, int y_choff,
+                           float* y2, int y2_stride, int y2_choff, int split_n, long long M, int N, hipStream_t st) {
+  if (!x || !w_packed || !ln_g || !ln_b || !y || M <= 0 || N <= 0 || N % 64 || ln_cols % 64 || (y2 && (split_n % 64 || split_n <= 0 || split_n >= N))) return LFSR_E_ARG;
+  if ((x_stride | x_choff | y_stride | y_choff) & 3 || (y2 && ((y2_stride | y2_choff) & 3)) || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
+  if (x_stride < x_choff + K || y_stride < y_choff + (y2 ? split_n : N) || (y2 && y2_stride < y2_choff + N - split_n)) return LFSR_E_ARG;
+  if (((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) return LFSR_E_ARG;
+  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  RowGemmArgs p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = 1.0f;
+  p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.ln_cols = ln_cols; p.pe = pe; p.pe_stride = pe_stride; p.pe_rows = pe_rows; p.pe_div = pe_div;
+  p.Y2 = y2; p.y2_stride = y2_stride; p.y2_choff = y2_choff; p.split_n = split_n;
+  switch (K) {
+    case 64: return launch_rowgemm<64, 64, 64, true>(p, st);
+    case 128: return launch_rowgemm<128, 64, 64, true>(p, st);
+    default: return LFSR_E_ARG;
+  }
 }
 
 int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* bias,
@@ -233,4 +297,12 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
     case 144: return launch_rowgemm<144, 64, 64>(p, st);
     default: return LFSR_E_ARG;
   }
+}
+
+extern "C" int lfsr_linear_ln_fwd(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* gamma, const float* beta,
+                                  float eps, int ln_cols, const float* pe, int pe_stride, int pe_rows, int pe_div,
+                                  float* y, int y_stride, int y_choff, float* y2, int y2_stride, int y2_choff, int split_n,
+                                  long long M, int N, void* stream) {
+  return lfsr_rowgemm_ln_launch(x, x_stride, x_choff, K, w_packed, gamma, beta, eps, ln_cols, pe, pe_stride, pe_rows, pe_div, y, y_stride, y_choff,
+                                y2, y2_stride, y2_choff, split_n, M, N, lfsr_stream(stream));
 }

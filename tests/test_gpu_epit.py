@@ -75,6 +75,56 @@ def test_ffn_fused(K1, H, M):
                             capi.dev_ptr(y), K1, 0, M, K1, H + 8, K1, 0.0, capi.stream_ptr()) == -1
 
 
+@pytest.mark.parametrize("K1,H,M", [(128, 256, 777), (64, 128, 2100), (128, 256, 70000)])
+def test_ffn_with_layernorm_inside(K1, H, M):
+    """y = res + W2 relu(W1 LayerNorm(x)) with the norm formed in registers (feed_forward.0 ... .4) against fp64 numpy; rows with a large common offset"""
+    lib = capi.load()
+    x, w1, w2 = rnd((M, K1), 24) + 3.0 * rnd((M, 1), 25), rnd((H, K1), 15, 0.1), rnd((K1, H), 16, 0.1)
+    g, b = (1.0 + 0.3 * rnd((K1,), 26)).astype(np.float32), rnd((K1,), 27, 0.2)
+    y = torch.empty(M, K1, device="cuda")
+    xd, gd, bd = dev(x), dev(g), dev(b)
+    w1p = capi.pack_conv_weight(dev(w1.reshape(H, K1, 1, 1)))
+    w2p = capi.pack_conv_weight(dev(w2.reshape(K1, H, 1, 1)))
+    capi.check(lib.lfsr_ffn_ln_fwd(capi.dev_ptr(xd), K1, 0, capi.dev_ptr(gd), capi.dev_ptr(bd), 1e-5, capi.dev_ptr(w1p), capi.dev_ptr(w2p), capi.dev_ptr(xd), K1, 0,
+                                   capi.dev_ptr(y), K1, 0, M, K1, H, K1, 0.0, capi.stream_ptr()), "ffn_ln")
+    x64 = x.astype(np.float64)
+    xn = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * g + b
+    ref = np.maximum(xn @ w1.astype(np.float64).T, 0.0) @ w2.astype(np.float64).T + x64
+    assert np.abs(y.cpu().numpy() - ref).max() < ATOL
+    assert lib.lfsr_ffn_ln_fwd(capi.dev_ptr(xd), K1, 0, None, capi.dev_ptr(bd), 1e-5, capi.dev_ptr(w1p), capi.dev_ptr(w2p), None, 0, 0,
+                               capi.dev_ptr(y), K1, 0, M, K1, H, K1, 0.0, capi.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize("K,M,with_pe", [(128, 5003, False), (128, 4096, True), (64, 5003, True), (64, 100, False)])
+def test_linear_with_layernorm_inside(K, M, with_pe):
+    """q | k from LayerNorm(x + pe), v from x in one launch: the same bits as lfsr_layernorm_fwd + two lfsr_linear_fwd"""
+    lib = capi.load()
+    N, split = 3 * K, 2 * K
+    x, w = rnd((M, K), 31) + 2.0 * rnd((M, 1), 32), rnd((N, K), 33, 0.1)
+    g, b = (1.0 + 0.3 * rnd((K,), 34)).astype(np.float32), rnd((K,), 35, 0.2)
+    pe_rows, pe_div = 7, 3
+    pe = rnd((pe_rows, K), 36)
+    xd, gd, bd, ped = dev(x), dev(g), dev(b), dev(pe)
+    wp = capi.pack_conv_weight(dev(w.reshape(N, K, 1, 1)))
+    qk, v = torch.empty(M, split, device="cuda"), torch.empty(M, N - split, device="cuda")
+    capi.check(lib.lfsr_linear_ln_fwd(capi.dev_ptr(xd), K, 0, K, capi.dev_ptr(wp), capi.dev_ptr(gd), capi.dev_ptr(bd), 1e-5, split,
+                                      capi.dev_ptr(ped) if with_pe else None, K, pe_rows, pe_div, capi.dev_ptr(qk), split, 0, capi.dev_ptr(v), N - split, 0, split,
+                                      M, N, capi.stream_ptr()), "linear_ln")
+    xn = torch.empty(M, K, device="cuda")
+    capi.check(lib.lfsr_layernorm_fwd(capi.dev_ptr(xd), K, 0, capi.dev_ptr(ped) if with_pe else None, K, pe_rows, pe_div, capi.dev_ptr(gd), capi.dev_ptr(bd),
+                                      capi.dev_ptr(xn), K, 0, M, K, 1e-5, capi.stream_ptr()), "ln")
+    x64 = x.astype(np.float64) + (pe[(np.arange(M) // pe_div) % pe_rows] if with_pe else 0.0)
+    ref_n = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * g + b
+    assert np.abs(qk.cpu().numpy() - ref_n @ w[:split].astype(np.float64).T).max() < ATOL
+    assert np.abs(v.cpu().numpy() - x.astype(np.float64) @ w[split:].astype(np.float64).T).max() < ATOL
+    if M >= 2048:      # (below that lfsr_linear_fwd runs the gather-GEMM, a different summation order)
+        qk2, v2 = torch.empty_like(qk), torch.empty_like(v)
+        capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xn), K, 0, K, capi.dev_ptr(wp), None, None, 0, 0, capi.dev_ptr(qk2), split, 0, M, split, 1.0, capi.stream_ptr()), "qk")
+        capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xd), K, 0, K, capi.dev_ptr(wp[split * K:]), None, None, 0, 0, capi.dev_ptr(v2), N - split, 0, M, N - split, 1.0,
+                                       capi.stream_ptr()), "v")
+        assert torch.equal(qk, qk2) and torch.equal(v, v2)
+
+
 @pytest.mark.parametrize("vertical", [0, 1])
 @pytest.mark.parametrize("geom", [(2, 3, 6, 8), (1, 5, 32, 32), (1, 5, 20, 32)])
 @pytest.mark.parametrize("path", ["mfma", "valu"])
@@ -129,8 +179,13 @@ def runtime(case, sd):
     return rt
 
 
+@pytest.mark.parametrize("ln_fuse", ["default", "0", "2"])   # feed-forward norm inside the FFN kernel (default) / every norm its own launch / attention norm inside q|k|v too
 @pytest.mark.parametrize("tag", TAGS)
-def test_epit_small_vs_golden_and_oracle(tag):
+def test_epit_small_vs_golden_and_oracle(tag, ln_fuse, monkeypatch):
+    if ln_fuse == "default":
+        monkeypatch.delenv("LFSR_LN_FUSE", raising=False)
+    else:
+        monkeypatch.setenv("LFSR_LN_FUSE", ln_fuse)
     case, sd, x, npz = model_case("EPIT", tag)
     y = runtime(case, sd).forward(dev(x)).cpu().numpy()
     gold = npz[tag + "_out"]

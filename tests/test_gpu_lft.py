@@ -58,8 +58,13 @@ def test_spatial_window_attention_vs_masked_mha():
     assert np.abs(o.cpu().numpy() - ref).max() < 1e-5
 
 
+@pytest.mark.parametrize("ln_fuse", ["default", "0", "2"])   # feed-forward norms inside the FFN kernels (default) / every norm its own launch / attention norms inside q|k|v too
 @pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
-def test_lft_small_vs_golden_and_oracle(tag):
+def test_lft_small_vs_golden_and_oracle(tag, ln_fuse, monkeypatch):
+    if ln_fuse == "default":
+        monkeypatch.delenv("LFSR_LN_FUSE", raising=False)
+    else:
+        monkeypatch.setenv("LFSR_LN_FUSE", ln_fuse)
     case, sd, x, npz = model_case("LFT", tag)
     y = runtime(case, sd).forward(dev(x)).cpu().numpy()
     gold = npz[tag + "_out"]
