@@ -189,6 +189,192 @@ __global__ __launch_bounds__(512) void k_up_tail(UpTailArgs p) {
   }
 }
 
+// ---- second form (default) ---------------------------------------------------------------------------------------------------------------------
+// Same tile and chunking, two changes.  (1) The 1x1 conv runs on 16 x 16 x 4 MFMAs: 13 row tiles (208 >= 204 px) x 4 column tiles = 52 items,
+// 13 per SIMD (the 32 x 32 form had 14 items: 4 / 4 / 3 / 3 per SIMD, and 224 rows).  (2) The 3x3 HR conv is gathered per LR pixel instead of per HR
+// output: thread (LR pixel, channel group) loads the (S+2) x (S+2) patch of U around its pixel once per channel -- S-wide rows as one 16-B / 8-B LDS
+// read -- and feeds all S^2 outputs of the pixel from registers (S = 4: 6 ds_read_b128 + 12 ds_read_b32 per channel against 144 ds_read_b32); the four
+// channel-group lanes of a pixel keep partial sums over their own channels for the whole kernel and are added once at the end.
+constexpr int UT2_ROWS = 208;
+
+template <int S>
+__global__ __launch_bounds__(512) void k_up_tail2(UpTailArgs p) {
+  constexpr int S2 = S * S, CC = 64 / S2, NCH = 64 / CC;   // channels per chunk, number of chunks
+  constexpr int CPT = CC / 4;                              // channels per thread and chunk (1 for S = 4, 4 for S = 2)
+  constexpr int PW = UT_X + 2;                             // halo tile width (34)
+  typedef float f32x4m __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smu[];
+  float* sF = smu;                                   // [UT2_ROWS][LDS_ROW]
+  float* sU = sF + UT2_ROWS * LDS_ROW;               // [UT2_ROWS][LDS_ROW]   U chunk, column n = dc*S2 + ij
+  float* sW = sU + UT2_ROWS * LDS_ROW;               // [2][64][LDS_ROW]
+  float* sW3 = sW + 2 * 64 * LDS_ROW;                // [64][9]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = tid & 15, r16 = tid >> 4;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int Hm = p.A * p.h, Wm = p.A * p.w, HW = p.h * p.w;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+  const int Y0 = ty * UT_Y, X0 = tx * UT_X;          // LR mosaic origin of the tile
+
+  for (int i = tid; i < 64 * 9; i += 512) sW3[i] = p.W3[i];
+  {   // F halo tile, zero outside the mosaic and in the padding rows: 208 x 16 float4 = 6.5 per thread, all loads before the first LDS store
+    float4 fv[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int idx = tid + 512 * q, px = idx >> 4, ch = idx & 15;
+      fv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (px < UT_PIX) {
+        int ly = px / PW, lx = px - ly * PW;
+        int Ym = Y0 + ly - 1, Xm = X0 + lx - 1;
+        if (Ym >= 0 && Ym < Hm && Xm >= 0 && Xm < Wm) {
+          int u = Ym / p.h, y = Ym - u * p.h, vv = Xm / p.w, x = Xm - vv * p.w;
+          long long pix = ((long long)b * p.A * p.A + u * p.A + vv) * HW + (long long)y * p.w + x;
+          fv[q] = *reinterpret_cast<const float4*>(p.F + pix * p.f_stride + p.f_choff + ch * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int idx = tid + 512 * q;
+      if ((idx >> 4) < UT2_ROWS) *reinterpret_cast<float4*>(sF + (idx >> 4) * LDS_ROW + (idx & 15) * 4) = fv[q];
+    }
+  }
+  auto wrow = [&](int cc, int r) -> const float* { int dc = r / S2, ij = r - dc * S2; return p.W0p + ((long long)(ij * 64 + cc * CC + dc)) * 64; };
+  float4 rw[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow(0, r16 + 32 * i) + c16 * 4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(sW + (r16 + 32 * i) * LDS_ROW + c16 * 4) = rw[i];
+  __syncthreads();
+
+  // phase-3 role: LR pixel pp of the 4 x 32 tile, channel group dcg (channels dcg*CPT .. +CPT-1 of every chunk)
+  const int dcg = tid & 3, pp = tid >> 2;
+  const int ply = 1 + pp / UT_X, plx = 1 + pp % UT_X;           // halo-tile coordinates of the pixel
+  const float* uC = sU + (ply * PW + plx) * LDS_ROW;            // its U row; neighbours at +-LDS_ROW (columns) and +-PW*LDS_ROW (rows)
+  float oacc[S2];
+#pragma unroll
+  for (int i = 0; i < S2; ++i) oacc[i] = 0.f;
+
+  for (int cc = 0; cc < NCH; ++cc) {
+    const float* sWc = sW + (cc & 1) * 64 * LDS_ROW;
+    if (cc + 1 < NCH) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rw[i] = *reinterpret_cast<const float4*>(wrow(cc + 1, r16 + 32 * i) + c16 * 4);
+    }
+    // ---- (1) U[px][n] = sum_k F[px][k] W[n][k]: item = (row tile of 16 px, column tile of 16); lane (l15, g) feeds k = 16 jj + 4 g + e of step (jj, e)
+    for (int item = wave; item < 52; item += 8) {
+      const int rt = item >> 2, ct = item & 3;
+      f32x4m acc = {0.f, 0.f, 0.f, 0.f};
+      const float* aRow = sF + (rt * 16 + l15) * LDS_ROW + 4 * g;
+      const float* bRow = sWc + (ct * 16 + l15) * LDS_ROW + 4 * g;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float4 a = *reinterpret_cast<const float4*>(aRow + 16 * jj);
+        const float4 bq = *reinterpret_cast<const float4*>(bRow + 16 * jj);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc, 0, 0, 0);
+      }
+      // (2) LeakyReLU -> sU ; D layout: row (pixel) = 4 g + r, column = l15
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[r];
+        sU[(rt * 16 + 4 * g + r) * LDS_ROW + ct * 16 + l15] = v >= 0.f ? v : v * p.slope;
+      }
+    }
+    if (cc + 1 < NCH) {
+      float* sWn = sW + ((cc + 1) & 1) * 64 * LDS_ROW;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(sWn + (r16 + 32 * i) * LDS_ROW + c16 * 4) = rw[i];
+    }
+    __syncthreads();
+    // ---- (3) 3x3 HR conv of this chunk's channels: patch P[py][px], HR offset (py - 1, px - 1) from the pixel's first sub-position ---------------
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      const int dc = dcg * CPT + e;
+      const float* uc = uC + dc * S2;
+      float P[S + 2][S + 2];
+#pragma unroll
+      for (int py = 0; py < S + 2; ++py) {
+        const int dy = py == 0 ? -1 : py == S + 1 ? 1 : 0, sy = py == 0 ? S - 1 : py == S + 1 ? 0 : py - 1;
+        const float* ur = uc + dy * PW * LDS_ROW + sy * S;
+        P[py][0] = ur[-LDS_ROW + S - 1];
+        P[py][S + 1] = ur[LDS_ROW];
+        if constexpr (S == 4) {
+          const float4 m = *reinterpret_cast<const float4*>(ur);
+          P[py][1] = m.x; P[py][2] = m.y; P[py][3] = m.z; P[py][4] = m.w;
+        } else {
+          const float2 m = *reinterpret_cast<const float2*>(ur);
+          P[py][1] = m.x; P[py][2] = m.y;
+        }
+      }
+      float wv[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) wv[q] = sW3[(cc * CC + dc) * 9 + q];
+#pragma unroll
+      for (int sy = 0; sy < S; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < S; ++sx) {
+          float a = oacc[sy * S + sx];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a = fmaf(P[sy + ky][sx + kx], wv[ky * 3 + kx], a);
+          oacc[sy * S + sx] = a;
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- sum over the four channel-group lanes of the pixel; lane dcg then owns S2 / 4 outputs: S = 4: sub-row dcg (4 consecutive HR columns); S = 2: sub-position dcg
+#pragma unroll
+  for (int i = 0; i < S2; ++i) {
+    oacc[i] += __shfl_xor(oacc[i], 1);
+    oacc[i] += __shfl_xor(oacc[i], 2);
+  }
+  const int Hs = Hm * S, Ws = Wm * S;
+  const float rs = 1.0f / (float)S;
+  const int Ylr = Y0 + ply - 1, Xlr = X0 + plx - 1;
+  if (Ylr >= Hm || Xlr >= Wm) return;
+  constexpr int NO = S2 / 4;
+  float res[NO];
+  const int sy_own = S == 4 ? dcg : dcg >> 1;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int sx = S == 4 ? j : (dcg & 1);
+    float sel = 0.f;
+#pragma unroll
+    for (int i = 0; i < S2; ++i) sel = (i == sy_own * S + sx) ? oacc[i] : sel;     // (register select: oacc is indexed by a lane-dependent value)
+    const int Y = Ylr * S + sy_own, X = Xlr * S + sx;
+    const int u = Y / (p.h * S), yl = Y - u * p.h * S, v = X / (p.w * S), xl = X - v * p.w * S;
+    const float sy = ((float)yl + 0.5f) * rs - 0.5f, sxf = ((float)xl + 0.5f) * rs - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sxf);
+    float cy[4], cx[4];
+    ut_cubic(sy - fy, cy);
+    ut_cubic(sxf - fx, cx);
+    const float* img = p.Xlr + (long long)b * Hm * Wm + (long long)(u * p.h) * Wm + v * p.w;
+    float up = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int iy = min(max((int)fy - 1 + q, 0), p.h - 1);
+      float rowv = 0.f;
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) {
+        int ix = min(max((int)fx - 1 + jx, 0), p.w - 1);
+        rowv = fmaf(cx[jx], img[(long long)iy * Wm + ix], rowv);
+      }
+      up = fmaf(cy[q], rowv, up);
+    }
+    res[j] = sel + up;
+  }
+  float* op = p.Out + ((long long)b * Hs + (Ylr * S + sy_own)) * Ws + (long long)Xlr * S;
+  if constexpr (S == 4) *reinterpret_cast<float4*>(op) = make_float4(res[0], res[1], res[2], res[3]);
+  else op[dcg & 1] = res[0];
+}
+
 }  // namespace
 
 extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const float* w0_packed, const float* w3, const float* x_lr, float* out,
@@ -211,6 +397,21 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
   p.tiles_y = (A * h + UT_Y - 1) / UT_Y; p.tiles_x = (A * w + UT_X - 1) / UT_X;
   long long grid = (long long)B * p.tiles_y * p.tiles_x;
   if (grid > 0x7fffffffLL) return LFSR_E_ARG;
+  const char* usel = getenv("LFSR_UPTAIL");         // "v1": the first form (A/B runs)
+  if (!(usel && usel[0] == 'v' && usel[1] == '1')) {
+    const int smem2 = (2 * UT2_ROWS * LDS_ROW + 2 * 64 * LDS_ROW + 64 * 9) * 4;
+    static std::atomic<bool> attr2_set[64];
+    if (!attr2_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail2<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+      if (e != hipSuccess) return LFSR_HIP_ERR(e);
+      attr2_set[dev] = true;
+    }
+    if (s == 2) hipLaunchKernelGGL((k_up_tail2<2>), dim3((unsigned)grid), dim3(512), smem2, lfsr_stream(stream), p);
+    else hipLaunchKernelGGL((k_up_tail2<4>), dim3((unsigned)grid), dim3(512), smem2, lfsr_stream(stream), p);
+    LFSR_CHECK_LAUNCH();
+    return LFSR_OK;
+  }
   if (s == 2) hipLaunchKernelGGL((k_up_tail<2>), dim3((unsigned)grid), dim3(512), smem, lfsr_stream(stream), p);
   else hipLaunchKernelGGL((k_up_tail<4>), dim3((unsigned)grid), dim3(512), smem, lfsr_stream(stream), p);
   LFSR_CHECK_LAUNCH();
