@@ -58,6 +58,29 @@ def test_spatial_window_attention_vs_masked_mha():
     assert np.abs(o.cpu().numpy() - ref).max() < 1e-5
 
 
+def test_angular_attention_vs_mha():
+    """AngTrans attention (LFT.py:236-241): the A*A views at one (y, x) are the sequence, 8 heads of 8, no mask; q | k read from one 128-wide buffer, token stride = one
+    view image -- the strided addressing lft.cpp uses -- against dense fp64 multi-head attention"""
+    lib = capi.load()
+    B, A, h, w, E, NH = 2, 3, 4, 6, 64, 8
+    AA, HW = A * A, h * w
+    npix = B * AA * HW
+    q, k, v = [(np.random.default_rng(s).standard_normal((npix, E))).astype(np.float32) for s in (11, 12, 13)]
+    qk = dev(np.concatenate([q, k], axis=1))
+    vd = dev(v)
+    o = torch.empty(npix, E, device="cuda")
+    capi.check(lib.lfsr_window_attn_fwd(capi.dev_ptr(qk), 2 * E, 0, capi.dev_ptr(qk), 2 * E, E, capi.dev_ptr(vd), E, 0, capi.dev_ptr(o), E, 0, NH, E // NH,
+                                        B, h, w, AA * HW, w, 1, AA, 1, HW, 0, AA, AA, 0, 1, 0, capi.stream_ptr()), "ang attn")
+    hd = E // NH
+    def seqs(t):      # (B, AA, HW, NH, hd) -> (B, HW, NH, AA, hd)
+        return t.astype(np.float64).reshape(B, AA, HW, NH, hd).transpose(0, 2, 3, 1, 4)
+    S = seqs(q) @ seqs(k).transpose(0, 1, 2, 4, 3) / np.sqrt(hd)
+    Pm = np.exp(S - S.max(-1, keepdims=True))
+    Pm /= Pm.sum(-1, keepdims=True)
+    ref = (Pm @ seqs(v)).transpose(0, 3, 1, 2, 4).reshape(npix, E)
+    assert np.abs(o.cpu().numpy() - ref).max() < 1e-5
+
+
 @pytest.mark.parametrize("ln_fuse", ["default", "0", "2"])   # feed-forward norms inside the FFN kernels (default) / every norm its own launch / attention norms inside q|k|v too
 @pytest.mark.parametrize("tag", ["a5h8s4", "a3h6w8s2"])
 def test_lft_small_vs_golden_and_oracle(tag, ln_fuse, monkeypatch):
