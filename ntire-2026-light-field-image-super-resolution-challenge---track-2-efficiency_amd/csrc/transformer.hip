@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void k_window_attn(AttnArgs p) {
 template <int HD, int HB>
 __global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, int ntile1) {
   extern __shared__ __attribute__((aligned(16))) float skv[];
-  constexpr int TS = HB * 2 * HD + 4;                 // floats per staged key token
+  constexpr int HS = 2 * HD + (HD == 8 ? 4 : 0);      // floats per staged (key, head): k | v; heads of 8 padded so that the eight heads of a key sit in disjoint banks
+  constexpr int TS = HB * HS + 4;                     // floats per staged key token
   const int hb = blockIdx.y * HB;                     // first head of this block
   int t = blockIdx.x;
   const int tile1 = t % ntile1; t /= ntile1;
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, in
   const int q_lo = tile1 * T1, q_hi = min(p.n1, q_lo + T1);
   const int k_lo = max(0, q_lo - p.l1), k_hi = min(p.n1, q_hi - 1 + p.r1);
   const int nkey = (k_hi - k_lo) * p.n2;
-  // stage K | V : one 16-B chunk per thread-iteration; chunk c of a (key, head): c < HD/4 -> K, else V
+  // stage K | V : one 16-B chunk per thread-iteration; chunk c of a (key, head): c < HD/4 -> K, else V.  (Issuing four loads before their four LDS stores was
+  // measured: 940 -> 1166 us for LFT's spatial attention -- the plain loop is already pipelined by the compiler)
   constexpr int CPT = 2 * HD / 4;                     // chunks per (key, head)
   for (int i = threadIdx.x; i < nkey * HB * CPT; i += blockDim.x) {
     int c = i % CPT, r = i / CPT, h = r % HB, key = r / HB;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, in
     long long pix = base + k1 * p.st1 + k2 * p.st2;
     const float* src = c < HD / 4 ? p.K + pix * p.k_stride + p.k_choff + (hb + h) * HD + c * 4
                                   : p.V + pix * p.v_stride + p.v_choff + (hb + h) * HD + (c - HD / 4) * 4;
-    *reinterpret_cast<float4*>(skv + key * TS + h * 2 * HD + c * 4) = *reinterpret_cast<const float4*>(src);
+    *reinterpret_cast<float4*>(skv + key * TS + h * HS + c * 4) = *reinterpret_cast<const float4*>(src);
   }
   __syncthreads();
   const int nq = (q_hi - q_lo) * p.n2;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, in
     const int a0 = max(0, t1 - p.l1), a1 = min(p.n1, t1 + p.r1);
     const int b0 = max(0, t2 - p.l2), b1 = min(min(p.n2, p.clip2), t2 + p.r2);
     for (int k1 = a0; k1 < a1; ++k1) {
-      const float* rowp = skv + ((k1 - k_lo) * p.n2) * TS + h * 2 * HD;
+      const float* rowp = skv + ((k1 - k_lo) * p.n2) * TS + h * HS;
       for (int k2 = b0; k2 < b1; ++k2) {
         const float4* kp = reinterpret_cast<const float4*>(rowp + k2 * TS);
         float s = 0.f;
@@ -352,6 +354,20 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
       if (threads > 1024) threads = 1024;
       dim3 grid((unsigned)((long long)ns0 * ns1 * ns2 * ntile1), (unsigned)(nheads / HB));
       hipLaunchKernelGGL((k_window_attn_lds<16, 2>), grid, dim3(threads), smem, lfsr_stream(stream), p, T1, ntile1);
+      LFSR_CHECK_LAUNCH();
+      return LFSR_OK;
+    }
+  }
+  // heads of 8, all eight in one block, whole (short) sequences: LFT's angular attention (25 views per pixel).  One block per sequence stages its 25 x (k | v) rows
+  // once; the L1-served kernel below re-reads them for every query (it ran at the L1's 64 B/clk: 0.43 ms per launch at 32 patches).  LFSR_ATTN_ANG=l1 keeps it (A/B runs)
+  if (hd == 8 && nheads == 8 && n2 == 1 && l1 >= n1 && r1 >= n1 && n1 <= 64 && !getenv("LFSR_ATTN_L1")) {
+    const char* asel = getenv("LFSR_ATTN_ANG");
+    if (!(asel && asel[0] == 'l' && asel[1] == '1')) {
+      constexpr int TS8 = 8 * 20 + 4;
+      const size_t smem = (size_t)n1 * TS8 * 4;
+      int threads = (n1 * 8 + 63) / 64 * 64;
+      dim3 grid((unsigned)((long long)ns0 * ns1 * ns2), 1);
+      hipLaunchKernelGGL((k_window_attn_lds<8, 8>), grid, dim3(threads), smem, lfsr_stream(stream), p, n1, 1);
       LFSR_CHECK_LAUNCH();
       return LFSR_OK;
     }
