@@ -290,6 +290,12 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
   // one call, profiles/r02_logs/ab_bench_lines.json: bench11_epit*.json): 637-639 patches/s against 659-660 for the 64 x 64 form -- one block per CU hides less HBM latency
   // than two; the 64 x 64 form stays the default
   const char* rsel = getenv("LFSR_ROWGEMM");
+  // the bias-free K = 64 / 128 linears (the transformers' projections) run on the bf16 MFMA pipe with their fp32 operands split EXACTLY into three bf16 terms
+  // (rowgemm_b3.hip; error against fp64 below this file's fp32-MFMA kernel: tools/b3_accuracy.py); LFSR_ROWGEMM=f32 keeps the fp32-MFMA form (A/B runs), 128 its wide tiles
+  if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !bias && (K == 64 || K == 128)) {
+    const int rc = lfsr_rowgemm_b3_launch(x, x_stride, x_choff, K, w_packed, res, res_stride, res_choff, y, y_stride, y_choff, M, N, slope, st);
+    if (rc != LFSR_E_ARG) return rc;
+  }
   const bool wide = N % 128 == 0 && rsel && rsel[0] == '1';
   switch (K) {
     case 64: return wide ? launch_rowgemm<64, 128, 128>(p, st) : launch_rowgemm<64, 64, 64>(p, st);

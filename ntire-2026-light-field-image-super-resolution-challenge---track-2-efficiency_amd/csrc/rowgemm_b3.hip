@@ -1,0 +1,187 @@
+// Row-streaming GEMM on the bf16 MFMA pipe with fp32 operands carried EXACTLY as three bf16 terms (opt-in: LFSR_ROWGEMM=b3).
+//   Y[m, n0:n0+64] = act(X[m, 0:K] W^T) (+res)        -- the transformer linears of EPIT.py:110-128 / LFT.py:188-246 (no bias)
+// x = x0 + x1 + x2 and w = w0 + w1 + w2 by truncation (each term a bf16, the sum exact); the six products of order <= 2 (x0w0, x0w1, x1w0, x1w1, x0w2, x2w0) run as
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the dropped terms are below 2^-24 relative, the dot product is closer to fp64 than an fp32 FMA chain
+// (tests/test_oracle_vs_golden.py::test_split_bf16_products).  Six K = 32 MFMAs of 17 cycles replace eight 16x16x4 fp32 MFMAs of 32 cycles: 2.5x less matrix-pipe time.
+// Structure: a persistent 256-thread block keeps the three bf16 planes of its 64 x K weight panel in LDS (split once per block from the packed fp32 weights); each wave
+// owns 16 token rows per tile and loads them straight from global memory in B-operand order (lane = row, eight consecutive k per k-group: two 16-B loads per K step),
+// splits them in registers (5.5 VALU per element) and runs 4 column sub-tiles x 6 products per K step.  No A image in LDS, no barrier in the tile loop.
+#include <stdlib.h>
+
+#include "lfsr_internal.h"
+
+namespace {
+
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+
+struct RowGemmB3Args {
+  const float* X; int x_stride; int x_choff;
+  const float* Wp;       // [N rows][K] fp32 (packed, k contiguous)
+  const float* R1; int r1_stride; int r1_choff;
+  float* Y; int y_stride; int y_choff;
+  long long M; int N;
+  float slope;
+};
+
+__device__ __forceinline__ unsigned b3_hi_pair(unsigned hi_src, unsigned lo_src) {      // (hi_src's upper half) << 16 | lo_src's upper half
+  return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u);
+}
+__device__ __forceinline__ float b3_residual(float a) { return a - __uint_as_float(__float_as_uint(a) & 0xffff0000u); }   // exact
+
+// eight consecutive floats -> their three bf16 planes in MFMA operand order (element j in half j & 1 of register j / 2)
+__device__ __forceinline__ void b3_split8(const float4 lo, const float4 hi, u32x4b& p0, u32x4b& p1, u32x4b& p2) {
+  const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  float r[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { r[j] = b3_residual(a[j]); q[j] = b3_residual(r[j]); }
+  p0 = u32x4b{b3_hi_pair(__float_as_uint(a[1]), __float_as_uint(a[0])), b3_hi_pair(__float_as_uint(a[3]), __float_as_uint(a[2])),
+              b3_hi_pair(__float_as_uint(a[5]), __float_as_uint(a[4])), b3_hi_pair(__float_as_uint(a[7]), __float_as_uint(a[6]))};
+  p1 = u32x4b{b3_hi_pair(__float_as_uint(r[1]), __float_as_uint(r[0])), b3_hi_pair(__float_as_uint(r[3]), __float_as_uint(r[2])),
+              b3_hi_pair(__float_as_uint(r[5]), __float_as_uint(r[4])), b3_hi_pair(__float_as_uint(r[7]), __float_as_uint(r[6]))};
+  p2 = u32x4b{b3_hi_pair(__float_as_uint(q[1]), __float_as_uint(q[0])), b3_hi_pair(__float_as_uint(q[3]), __float_as_uint(q[2])),
+              b3_hi_pair(__float_as_uint(q[5]), __float_as_uint(q[4])), b3_hi_pair(__float_as_uint(q[7]), __float_as_uint(q[6]))};
+}
+
+// asm MFMA with the accumulator tied (see conv3x3_wino4b.hip: the builtin's register allocation may overlap vDst with a source partially)
+__device__ __forceinline__ void b3_mfma(f32x4b& c, const u32x4b a, const u32x4b b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
+  constexpr int NB = 64, BMR = 64;
+  constexpr int KS = K / 32;                // K steps
+  constexpr int LRH = K + 8;                // LDS row stride in bf16 (2 K + 16 bytes: 16 consecutive rows start in distinct 16-B slots)
+  constexpr int PLANE = NB * LRH;           // bf16 per plane
+  extern __shared__ __attribute__((aligned(16))) unsigned short swb[];     // [3][NB][LRH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * NB;
+  const long long ntiles = (p.M + BMR - 1) / BMR;
+
+  // the block's weight panel: split into planes, 8 consecutive k per thread-iteration
+  for (int i = tid; i < NB * (K / 8); i += 256) {
+    const int r = i / (K / 8), c = i - r * (K / 8);
+    const bool ok = n0 + r < p.N;
+    const float* src = p.Wp + (long long)(ok ? n0 + r : 0) * K + c * 8;
+    float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    if (!ok) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
+    u32x4b w0, w1, w2;
+    b3_split8(lo, hi, w0, w1, w2);
+    *reinterpret_cast<u32x4b*>(swb + 0 * PLANE + r * LRH + c * 8) = w0;
+    *reinterpret_cast<u32x4b*>(swb + 1 * PLANE + r * LRH + c * 8) = w1;
+    *reinterpret_cast<u32x4b*>(swb + 2 * PLANE + r * LRH + c * 8) = w2;
+  }
+  __syncthreads();
+
+  // this lane's token row of a tile and its 8-float groups: rows past M read as zero through the buffer descriptor
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)(p.M * p.x_stride * 4), 0x00020000);
+  const int offL = ((wave * 16 + l15) * p.x_stride + p.x_choff + 8 * g) * 4;
+  float4 xr[KS][2];
+  auto prefetch = [&](long long tile) {
+    const int s4 = (int)(tile * BMR) * p.x_stride * 4;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offL + (32 * s + 4 * e) * 4, s4, 0));
+        xr[s][e] = make_float4(v.x, v.y, v.z, v.w);
+      }
+  };
+  long long tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile);
+  const unsigned short* wl = swb + l15 * LRH + 8 * g;          // this lane's A-operand slot: weight row l15 (+16 per sub-tile), k-group g
+  for (; tile < ntiles; tile += gridDim.x) {
+    u32x4b x0[KS], x1[KS], x2[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b3_split8(xr[s][0], xr[s][1], x0[s], x1[s], x2[s]);
+    if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    f32x4b acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_nop 4");                 // (the split's VALU results feed the asm MFMAs below: the compiler does not see an MFMA there)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const unsigned short* wq = wl + t * 16 * LRH + 32 * s;
+        const u32x4b w0 = *reinterpret_cast<const u32x4b*>(wq);
+        const u32x4b w1 = *reinterpret_cast<const u32x4b*>(wq + PLANE);
+        const u32x4b w2 = *reinterpret_cast<const u32x4b*>(wq + 2 * PLANE);
+        // D[channel][row]: A = the weight rows, B = the token rows.  Smallest terms first.
+        b3_mfma(acc[t], w2, x0[s]);
+        b3_mfma(acc[t], w0, x2[s]);
+        b3_mfma(acc[t], w1, x1[s]);
+        b3_mfma(acc[t], w1, x0[s]);
+        b3_mfma(acc[t], w0, x1[s]);
+        b3_mfma(acc[t], w0, x0[s]);
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15");      // MFMA results -> VALU reads below (the hazard the compiler would pad for a builtin)
+    // epilogue: lane (row l15, g) holds channels n0 + 16 t + 4 g .. + 3 of its row
+    const long long m = tile * BMR + wave * 16 + l15;
+    if (m < p.M) {
+      float4 rv[4];
+      if (p.R1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int n = n0 + 16 * t + 4 * g;
+          rv[t] = n + 3 < p.N ? *reinterpret_cast<const float4*>(p.R1 + m * p.r1_stride + p.r1_choff + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n = n0 + 16 * t + 4 * g;
+        if (n + 3 >= p.N) continue;
+        float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+        if (p.R1) { v[0] += rv[t].x; v[1] += rv[t].y; v[2] += rv[t].z; v[3] += rv[t].w; }
+        *reinterpret_cast<float4*>(p.Y + m * p.y_stride + p.y_choff + n) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <int K>
+int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
+  constexpr int smem = 3 * 64 * (K + 8) * 2;
+  constexpr int per_cu = smem <= 52 * 1024 ? 3 : 2;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm_b3<K>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  const long long ntiles = (p.M + 63) / 64;
+  const int nby = (p.N + 63) / 64;
+  int gx = 256 * per_cu / nby;
+  if (gx > 8) gx &= ~7;
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = (int)ntiles;
+  hipLaunchKernelGGL((k_rowgemm_b3<K>), dim3((unsigned)gx, (unsigned)nby), dim3(256), smem, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+}  // namespace
+
+// LFSR_E_ARG = shape not covered (the caller runs the fp32-MFMA row-GEMM)
+int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* res, int res_stride, int res_choff,
+                           float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st) {
+  if ((x_stride | x_choff) & 3 || N % 64 || (y_stride | y_choff) & 3 || (res && ((res_stride | res_choff) & 3))) return LFSR_E_ARG;
+  if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)res | (uintptr_t)w_packed) & 15) return LFSR_E_ARG;
+  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  RowGemmB3Args p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
+  p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = slope;
+  switch (K) {
+    case 64: return launch_b3<64>(p, st);
+    case 128: return launch_b3<128>(p, st);
+    default: return LFSR_E_ARG;
+  }
+}

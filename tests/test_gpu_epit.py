@@ -45,7 +45,7 @@ def test_linear(cin, N, slope, M, monkeypatch):
     x, w, r, b = rnd((M, cin), 4), rnd((N, cin), 5, 0.1), rnd((M, N), 6), rnd((N,), 7)
     xd, rd, bd, wp = dev(x), dev(r), dev(b), capi.pack_conv_weight(dev(w.reshape(N, cin, 1, 1)))
     z = x.astype(np.float64) @ w.astype(np.float64).T
-    for sel in ("", "128"):      # LFSR_ROWGEMM=128 selects the 128 x 128 tiles where N allows (the 64 x 64 form is the default)
+    for sel in ("", "f32", "128"):      # default: exact three-term bf16 operands on the bf16 MFMA pipe where K = 64 / 128 and there is no bias; f32: the fp32-MFMA form; 128: its 128 x 128 tiles
         monkeypatch.setenv("LFSR_ROWGEMM", sel)
         for use_r, use_b in ((True, False), (False, True), (False, False)):
             y = torch.full((M, N), float("nan"), device="cuda")
@@ -96,8 +96,9 @@ def test_ffn_with_layernorm_inside(K1, H, M):
 
 
 @pytest.mark.parametrize("K,M,with_pe", [(128, 5003, False), (128, 4096, True), (64, 5003, True), (64, 100, False)])
-def test_linear_with_layernorm_inside(K, M, with_pe):
-    """q | k from LayerNorm(x + pe), v from x in one launch: the same bits as lfsr_layernorm_fwd + two lfsr_linear_fwd"""
+def test_linear_with_layernorm_inside(K, M, with_pe, monkeypatch):
+    """q | k from LayerNorm(x + pe), v from x in one launch: the same bits as lfsr_layernorm_fwd + two lfsr_linear_fwd (fp32-MFMA form)"""
+    monkeypatch.setenv("LFSR_ROWGEMM", "f32")
     lib = capi.load()
     N, split = 3 * K, 2 * K
     x, w = rnd((M, K), 31) + 2.0 * rnd((M, 1), 32), rnd((N, K), 33, 0.1)
