@@ -124,6 +124,10 @@ int lfsr_ffn_ln_launch(const float* x, int x_stride, int x_choff, const float* l
                        const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
                        long long M, int K1, int H, int N2, float slope, hipStream_t st);
 
+int lfsr_ffn_b3_launch(const float* x, int x_stride, int x_choff, const float* ln_g, const float* ln_b, float ln_eps, const float* w1_packed, const float* w2_packed,
+                       const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
+                       long long M, int K1, int H, int N2, float slope, hipStream_t st);
+
 // attn_mfma.hip: EPI attention on MFMA; LFSR_E_ARG = geometry not covered
 int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,
                               float* o, int o_stride, int o_choff, int nheads, int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
