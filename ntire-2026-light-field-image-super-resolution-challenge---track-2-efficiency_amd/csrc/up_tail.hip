@@ -189,7 +189,56 @@ __global__ __launch_bounds__(512) void k_up_tail(UpTailArgs p) {
   }
 }
 
-// ---- second form (default) ---------------------------------------------------------------------------------------------------------------------
+// output stage shared by the second and third form: sum over the four channel-group lanes of the pixel, + per-view bicubic skip, store
+template <int S>
+__device__ __forceinline__ void ut_tail_store(const UpTailArgs& p, float (&oacc)[S * S], int dcg, int b, int Ylr, int Xlr, int Hm, int Wm) {
+  constexpr int S2 = S * S;
+  // ---- sum over the four channel-group lanes of the pixel; lane dcg then owns S2 / 4 outputs: S = 4: sub-row dcg (4 consecutive HR columns); S = 2: sub-position dcg
+#pragma unroll
+  for (int i = 0; i < S2; ++i) {
+    oacc[i] += __shfl_xor(oacc[i], 1);
+    oacc[i] += __shfl_xor(oacc[i], 2);
+  }
+  const int Hs = Hm * S, Ws = Wm * S;
+  const float rs = 1.0f / (float)S;
+  if (Ylr >= Hm || Xlr >= Wm) return;
+  constexpr int NO = S2 / 4;
+  float res[NO];
+  const int sy_own = S == 4 ? dcg : dcg >> 1;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) {
+    const int sx = S == 4 ? j : (dcg & 1);
+    float sel = 0.f;
+#pragma unroll
+    for (int i = 0; i < S2; ++i) sel = (i == sy_own * S + sx) ? oacc[i] : sel;     // (register select: oacc is indexed by a lane-dependent value)
+    const int Y = Ylr * S + sy_own, X = Xlr * S + sx;
+    const int u = Y / (p.h * S), yl = Y - u * p.h * S, v = X / (p.w * S), xl = X - v * p.w * S;
+    const float sy = ((float)yl + 0.5f) * rs - 0.5f, sxf = ((float)xl + 0.5f) * rs - 0.5f;
+    const float fy = floorf(sy), fx = floorf(sxf);
+    float cy[4], cx[4];
+    ut_cubic(sy - fy, cy);
+    ut_cubic(sxf - fx, cx);
+    const float* img = p.Xlr + (long long)b * Hm * Wm + (long long)(u * p.h) * Wm + v * p.w;
+    float up = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int iy = min(max((int)fy - 1 + q, 0), p.h - 1);
+      float rowv = 0.f;
+#pragma unroll
+      for (int jx = 0; jx < 4; ++jx) {
+        int ix = min(max((int)fx - 1 + jx, 0), p.w - 1);
+        rowv = fmaf(cx[jx], img[(long long)iy * Wm + ix], rowv);
+      }
+      up = fmaf(cy[q], rowv, up);
+    }
+    res[j] = sel + up;
+  }
+  float* op = p.Out + ((long long)b * Hs + (Ylr * S + sy_own)) * Ws + (long long)Xlr * S;
+  if constexpr (S == 4) *reinterpret_cast<float4*>(op) = make_float4(res[0], res[1], res[2], res[3]);
+  else op[dcg & 1] = res[0];
+}
+
+// ---- second form (LFSR_UPTAIL=v2) ---------------------------------------------------------------------------------------------------------------------
 // Same tile and chunking, two changes.  (1) The 1x1 conv runs on 16 x 16 x 4 MFMAs: 13 row tiles (208 >= 204 px) x 4 column tiles = 52 items,
 // 13 per SIMD (the 32 x 32 form had 14 items: 4 / 4 / 3 / 3 per SIMD, and 224 rows).  (2) The 3x3 HR conv is gathered per LR pixel instead of per HR
 // output: thread (LR pixel, channel group) loads the (S+2) x (S+2) patch of U around its pixel once per channel -- S-wide rows as one 16-B / 8-B LDS
@@ -329,50 +378,174 @@ __global__ __launch_bounds__(512) void k_up_tail2(UpTailArgs p) {
     __syncthreads();
   }
 
-  // ---- sum over the four channel-group lanes of the pixel; lane dcg then owns S2 / 4 outputs: S = 4: sub-row dcg (4 consecutive HR columns); S = 2: sub-position dcg
+  ut_tail_store<S>(p, oacc, dcg, b, Y0 + ply - 1, X0 + plx - 1, Hm, Wm);
+}
+
+// ---- third form (default): the 1x1 conv on the bf16 MFMA pipe with exact three-term operands -------------------------------------------------------
+// As k_up_tail2, but U = F W^T runs as v_mfma_f32_16x16x32_bf16 on fp32 operands split by truncation into three bf16 terms (six products of order <= 2,
+// fp32 accumulation; see rowgemm_b3.hip).  The feature tile never enters LDS: a wave owns up to four (16-pixel row tile, 32-column half) units for all chunks
+// and keeps the three planes of its row tiles' features in registers (B... A-operand order, loaded straight from global memory with the halo / zero logic);
+// the weight chunks are split into planes while they are staged (double-buffered).  26 units over 8 waves = 7 / 7 / 6 / 6 per SIMD, 12 MFMAs of 17 cycles per
+// unit and K step against 16 of 32.
+typedef unsigned u32x4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned ut_hi_pair(unsigned hi_src, unsigned lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
+__device__ __forceinline__ float ut_residual(float a) { return a - __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
+__device__ __forceinline__ void ut_split8(const float4 lo, const float4 hi, u32x4u& p0, u32x4u& p1, u32x4u& p2) {
+  const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  float r[8], q[8];
 #pragma unroll
-  for (int i = 0; i < S2; ++i) {
-    oacc[i] += __shfl_xor(oacc[i], 1);
-    oacc[i] += __shfl_xor(oacc[i], 2);
-  }
-  const int Hs = Hm * S, Ws = Wm * S;
-  const float rs = 1.0f / (float)S;
-  const int Ylr = Y0 + ply - 1, Xlr = X0 + plx - 1;
-  if (Ylr >= Hm || Xlr >= Wm) return;
-  constexpr int NO = S2 / 4;
-  float res[NO];
-  const int sy_own = S == 4 ? dcg : dcg >> 1;
+  for (int j = 0; j < 8; ++j) { r[j] = ut_residual(a[j]); q[j] = ut_residual(r[j]); }
+  p0 = u32x4u{ut_hi_pair(__float_as_uint(a[1]), __float_as_uint(a[0])), ut_hi_pair(__float_as_uint(a[3]), __float_as_uint(a[2])),
+              ut_hi_pair(__float_as_uint(a[5]), __float_as_uint(a[4])), ut_hi_pair(__float_as_uint(a[7]), __float_as_uint(a[6]))};
+  p1 = u32x4u{ut_hi_pair(__float_as_uint(r[1]), __float_as_uint(r[0])), ut_hi_pair(__float_as_uint(r[3]), __float_as_uint(r[2])),
+              ut_hi_pair(__float_as_uint(r[5]), __float_as_uint(r[4])), ut_hi_pair(__float_as_uint(r[7]), __float_as_uint(r[6]))};
+  p2 = u32x4u{ut_hi_pair(__float_as_uint(q[1]), __float_as_uint(q[0])), ut_hi_pair(__float_as_uint(q[3]), __float_as_uint(q[2])),
+              ut_hi_pair(__float_as_uint(q[5]), __float_as_uint(q[4])), ut_hi_pair(__float_as_uint(q[7]), __float_as_uint(q[6]))};
+}
+typedef float f32x4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ut_mfma(f32x4u& c, const u32x4u a, const u32x4u b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+template <int S>
+__global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
+  constexpr int S2 = S * S, CC = 64 / S2, NCH = 64 / CC;
+  constexpr int CPT = CC / 4;
+  constexpr int PW = UT_X + 2;
+  constexpr int WRH = 72;                             // bf16 per weight row in LDS (64 + 8: 16 consecutive rows start in distinct 16-B slots)
+  constexpr int WPL = 64 * WRH;                       // bf16 per weight plane
+  extern __shared__ __attribute__((aligned(16))) float smu[];
+  float* sU = smu;                                    // [UT2_ROWS][LDS_ROW]   U chunk, column n = dc*S2 + ij
+  float* sW3 = sU + UT2_ROWS * LDS_ROW;               // [64][9]
+  unsigned short* sWb = reinterpret_cast<unsigned short*>(sW3 + 64 * 9);   // [2][3][64][WRH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int Hm = p.A * p.h, Wm = p.A * p.w, HW = p.h * p.w;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+  const int Y0 = ty * UT_Y, X0 = tx * UT_X;
+
+  for (int i = tid; i < 64 * 9; i += 512) sW3[i] = p.W3[i];
+  // weight chunk cc: LDS row (dc*S2 + ij) <- packed row (ij*64 + cc*CC + dc); thread = (row r = tid >> 3, eight consecutive k: tid & 7), split while staged
+  const int wr = tid >> 3, wk = tid & 7;
+  auto wsrc = [&](int cc) -> const float* { int dc = wr / S2, ij = wr - dc * S2; return p.W0p + ((long long)(ij * 64 + cc * CC + dc)) * 64 + wk * 8; };
+  float4 rw[2];
+  auto fetch_w = [&](int cc) { const float* s0 = wsrc(cc); rw[0] = *reinterpret_cast<const float4*>(s0); rw[1] = *reinterpret_cast<const float4*>(s0 + 4); };
+  auto store_w = [&](int bufi) {
+    u32x4u p0, p1, p2;
+    ut_split8(rw[0], rw[1], p0, p1, p2);
+    unsigned short* d = sWb + bufi * 3 * WPL + wr * WRH + wk * 8;
+    *reinterpret_cast<u32x4u*>(d) = p0; *reinterpret_cast<u32x4u*>(d + WPL) = p1; *reinterpret_cast<u32x4u*>(d + 2 * WPL) = p2;
+  };
+  fetch_w(0);
+
+  // this wave's units u = wave + 8 i (i < 4, u < 26): row tile u >> 1, column half u & 1; the feature planes of its row tiles, B-operand order: lane (pixel l15, k-group g)
+  u32x4u f0[4][2], f1[4][2], f2[4][2];
 #pragma unroll
-  for (int j = 0; j < NO; ++j) {
-    const int sx = S == 4 ? j : (dcg & 1);
-    float sel = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int u = wave + 8 * i;
+    const int px = (u >> 1) * 16 + l15;
+    float4 v[2][2];
 #pragma unroll
-    for (int i = 0; i < S2; ++i) sel = (i == sy_own * S + sx) ? oacc[i] : sel;     // (register select: oacc is indexed by a lane-dependent value)
-    const int Y = Ylr * S + sy_own, X = Xlr * S + sx;
-    const int u = Y / (p.h * S), yl = Y - u * p.h * S, v = X / (p.w * S), xl = X - v * p.w * S;
-    const float sy = ((float)yl + 0.5f) * rs - 0.5f, sxf = ((float)xl + 0.5f) * rs - 0.5f;
-    const float fy = floorf(sy), fx = floorf(sxf);
-    float cy[4], cx[4];
-    ut_cubic(sy - fy, cy);
-    ut_cubic(sxf - fx, cx);
-    const float* img = p.Xlr + (long long)b * Hm * Wm + (long long)(u * p.h) * Wm + v * p.w;
-    float up = 0.f;
+    for (int s = 0; s < 2; ++s) { v[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); v[s][1] = v[s][0]; }
+    if (u < 26 && px < UT_PIX) {
+      const int ly = px / PW, lx = px - ly * PW;
+      const int Ym = Y0 + ly - 1, Xm = X0 + lx - 1;
+      if (Ym >= 0 && Ym < Hm && Xm >= 0 && Xm < Wm) {
+        const int uu = Ym / p.h, y = Ym - uu * p.h, vv = Xm / p.w, x = Xm - vv * p.w;
+        const long long pix = ((long long)b * p.A * p.A + uu * p.A + vv) * HW + (long long)y * p.w + x;
+        const float* src = p.F + pix * p.f_stride + p.f_choff + 8 * g;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int iy = min(max((int)fy - 1 + q, 0), p.h - 1);
-      float rowv = 0.f;
-#pragma unroll
-      for (int jx = 0; jx < 4; ++jx) {
-        int ix = min(max((int)fx - 1 + jx, 0), p.w - 1);
-        rowv = fmaf(cx[jx], img[(long long)iy * Wm + ix], rowv);
+        for (int s = 0; s < 2; ++s) { v[s][0] = *reinterpret_cast<const float4*>(src + 32 * s); v[s][1] = *reinterpret_cast<const float4*>(src + 32 * s + 4); }
       }
-      up = fmaf(cy[q], rowv, up);
     }
-    res[j] = sel + up;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) ut_split8(v[s][0], v[s][1], f0[i][s], f1[i][s], f2[i][s]);
   }
-  float* op = p.Out + ((long long)b * Hs + (Ylr * S + sy_own)) * Ws + (long long)Xlr * S;
-  if constexpr (S == 4) *reinterpret_cast<float4*>(op) = make_float4(res[0], res[1], res[2], res[3]);
-  else op[dcg & 1] = res[0];
+  store_w(0);
+  __syncthreads();
+
+  const int dcg = tid & 3, pp = tid >> 2;
+  const int ply = 1 + pp / UT_X, plx = 1 + pp % UT_X;
+  const float* uC = sU + (ply * PW + plx) * LDS_ROW;
+  float oacc[S2];
+#pragma unroll
+  for (int i = 0; i < S2; ++i) oacc[i] = 0.f;
+
+  for (int cc = 0; cc < NCH; ++cc) {
+    const unsigned short* sWc = sWb + (cc & 1) * 3 * WPL;
+    if (cc + 1 < NCH) fetch_w(cc + 1);
+    // ---- (1) U[px][n]: D[weight row n][pixel]: lane (pixel l15, g) receives columns n = 16 ct + 4 g + r of its pixel
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = wave + 8 * i;
+      if (u < 26) {
+        const int rt = u >> 1, ch = u & 1;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const int ct = 2 * ch + c2;
+          f32x4u acc = {0.f, 0.f, 0.f, 0.f};
+          asm volatile("s_nop 1" : "+v"(acc));
+          const unsigned short* wq = sWc + (ct * 16 + l15) * WRH + 8 * g;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const u32x4u w0 = *reinterpret_cast<const u32x4u*>(wq + 32 * s);
+            const u32x4u w1 = *reinterpret_cast<const u32x4u*>(wq + 32 * s + WPL);
+            const u32x4u w2 = *reinterpret_cast<const u32x4u*>(wq + 32 * s + 2 * WPL);
+            ut_mfma(acc, w2, f0[i][s]); ut_mfma(acc, w0, f2[i][s]); ut_mfma(acc, w1, f1[i][s]);
+            ut_mfma(acc, w1, f0[i][s]); ut_mfma(acc, w0, f1[i][s]); ut_mfma(acc, w0, f0[i][s]);
+          }
+          asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+          // (2) LeakyReLU -> sU: four consecutive columns of one pixel: one 16-B store
+          float4 o;
+          o.x = acc[0] >= 0.f ? acc[0] : acc[0] * p.slope; o.y = acc[1] >= 0.f ? acc[1] : acc[1] * p.slope;
+          o.z = acc[2] >= 0.f ? acc[2] : acc[2] * p.slope; o.w = acc[3] >= 0.f ? acc[3] : acc[3] * p.slope;
+          *reinterpret_cast<float4*>(sU + (rt * 16 + l15) * LDS_ROW + ct * 16 + 4 * g) = o;
+        }
+      }
+    }
+    if (cc + 1 < NCH) store_w((cc + 1) & 1);
+    __syncthreads();
+    // ---- (3) 3x3 HR conv of this chunk's channels, as in k_up_tail2 ------------------------------------------------------------------------------
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      const int dc = dcg * CPT + e;
+      const float* uc = uC + dc * S2;
+      float P[S + 2][S + 2];
+#pragma unroll
+      for (int py = 0; py < S + 2; ++py) {
+        const int dy = py == 0 ? -1 : py == S + 1 ? 1 : 0, sy = py == 0 ? S - 1 : py == S + 1 ? 0 : py - 1;
+        const float* ur = uc + dy * PW * LDS_ROW + sy * S;
+        P[py][0] = ur[-LDS_ROW + S - 1];
+        P[py][S + 1] = ur[LDS_ROW];
+        if constexpr (S == 4) {
+          const float4 m = *reinterpret_cast<const float4*>(ur);
+          P[py][1] = m.x; P[py][2] = m.y; P[py][3] = m.z; P[py][4] = m.w;
+        } else {
+          const float2 m = *reinterpret_cast<const float2*>(ur);
+          P[py][1] = m.x; P[py][2] = m.y;
+        }
+      }
+      float wv[9];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) wv[q] = sW3[(cc * CC + dc) * 9 + q];
+#pragma unroll
+      for (int sy = 0; sy < S; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < S; ++sx) {
+          float a = oacc[sy * S + sx];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a = fmaf(P[sy + ky][sx + kx], wv[ky * 3 + kx], a);
+          oacc[sy * S + sx] = a;
+        }
+    }
+    __syncthreads();
+  }
+  ut_tail_store<S>(p, oacc, dcg, b, Y0 + ply - 1, X0 + plx - 1, Hm, Wm);
 }
 
 }  // namespace
@@ -397,8 +570,23 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
   p.tiles_y = (A * h + UT_Y - 1) / UT_Y; p.tiles_x = (A * w + UT_X - 1) / UT_X;
   long long grid = (long long)B * p.tiles_y * p.tiles_x;
   if (grid > 0x7fffffffLL) return LFSR_E_ARG;
-  const char* usel = getenv("LFSR_UPTAIL");         // "v1": the first form (A/B runs)
-  if (!(usel && usel[0] == 'v' && usel[1] == '1')) {
+  const char* usel = getenv("LFSR_UPTAIL");         // "v1" / "v2": the first / second (fp32-MFMA) forms (A/B runs)
+  if (!(usel && usel[0] == 'v')) {
+    const int smem3 = (UT2_ROWS * LDS_ROW + 64 * 9) * 4 + 2 * 3 * 64 * 72 * 2;
+    static std::atomic<bool> attr3_set[64];
+    if (!attr3_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail3<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
+      if (e != hipSuccess) return LFSR_HIP_ERR(e);
+      attr3_set[dev] = true;
+    }
+    if (((uintptr_t)f | (uintptr_t)w0_packed) & 15) return LFSR_E_ARG;
+    if (s == 2) hipLaunchKernelGGL((k_up_tail3<2>), dim3((unsigned)grid), dim3(512), smem3, lfsr_stream(stream), p);
+    else hipLaunchKernelGGL((k_up_tail3<4>), dim3((unsigned)grid), dim3(512), smem3, lfsr_stream(stream), p);
+    LFSR_CHECK_LAUNCH();
+    return LFSR_OK;
+  }
+  if (!(usel[1] == '1')) {
     const int smem2 = (2 * UT2_ROWS * LDS_ROW + 2 * 64 * LDS_ROW + 64 * 9) * 4;
     static std::atomic<bool> attr2_set[64];
     if (!attr2_set[dev]) {
