@@ -291,6 +291,12 @@ def bench_model(args, rank, world, dev, dist):
         if name == "lft":
             line["scaling"] = "strong"
         line["model_tflops_windowed"] = FLOP_PER_PATCH[name] * line["value"] / 1e12
+        # the arithmetic the transformer GEMMs run in (rowgemm_b3.hip / ffn_b3.hip / up_tail.hip): fp32 operands split EXACTLY into three bf16 terms, six
+        # products on the bf16 MFMA pipe, fp32 accumulation -- error against fp64 below the fp32-MFMA kernels' (tools/b3_accuracy.py); LFSR_ROWGEMM=f32
+        # LFSR_FFN=f32 LFSR_UPTAIL=v2 select the fp32-MFMA kernels
+        f32_sel = [os.environ.get("LFSR_ROWGEMM", "")[:1] in ("f", "1"), os.environ.get("LFSR_FFN", "")[:1] == "f", os.environ.get("LFSR_UPTAIL", "")[:1] == "v"]
+        line["dtype"] = "f32" if all(f32_sel) else "f32 (linear / FFN / tail GEMMs: fp32 operands as three exact bf16 terms on the bf16 MFMA pipe, fp32 accumulation; 3x3 convs and attention: fp32 MFMA)"
+        line["config"]["gemm_arithmetic"] = {"rowgemm": "f32" if f32_sel[0] else "bf16x3", "ffn": "f32" if f32_sel[1] else "bf16x3", "up_tail": "f32" if f32_sel[2] else "bf16x3"}
         print(json.dumps(line), flush=True)
     finish(dist)
 
