@@ -179,6 +179,8 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
       }
 #pragma unroll
       for (int s = 0; s < KS1; ++s) c3_split8(xr[s], x0[s], x1[s], x2[s]);
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) asm volatile("s_nop 4" : "+v"(x0[s]), "+v"(x1[s]), "+v"(x2[s]));
     }
 #pragma unroll
     for (int t = 0; t < NT2; ++t)
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
           for (int j = 0; j < 8; ++j) { const float v = h[8 * ks + j]; hv[j] = v >= 0.f ? v : v * p.slope; }
           c3_split8(hv, h0[ks], h1[ks], h2[ks]);
         }
-        asm volatile("s_nop 4" : "+v"(h0[0]), "+v"(h0[1]));
+        asm volatile("s_nop 4" : "+v"(h0[0]), "+v"(h0[1]), "+v"(h1[0]), "+v"(h1[1]), "+v"(h2[0]), "+v"(h2[1]));   // every plane tied: no split instruction may sink behind the wait
         // GEMM 2 (transposed): y[n][row] += W2[n][hidden chunk] h[hidden][row]
         const unsigned short* a2 = buf + 3 * P1 + l31 * R2H + 8 * half;
 #pragma unroll

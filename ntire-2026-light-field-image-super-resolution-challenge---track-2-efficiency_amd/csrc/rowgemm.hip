@@ -261,6 +261,14 @@ int lfsr_rowgemm_ln_launch(const float* x, int x_stride, int x_choff, int K, con
   if (x_stride < x_choff + K || y_stride < y_choff + (y2 ? split_n : N) || (y2 && y2_stride < y2_choff + N - split_n)) return LFSR_E_ARG;
   if (((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) return LFSR_E_ARG;
   if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  {   // default: the three-term bf16 form (rowgemm_b3.hip); LFSR_ROWGEMM=f32 keeps the fp32-MFMA kernel below (bit-identical to LayerNorm launch + fp32 row-GEMM)
+    const char* rsel = getenv("LFSR_ROWGEMM");
+    if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1'))) {
+      const int rc = lfsr_rowgemm_b3_ln_launch(x, x_stride, x_choff, K, w_packed, ln_g, ln_b, ln_eps, ln_cols, pe, pe_stride, pe_rows, pe_div, y, y_stride, y_choff,
+                                               y2, y2_stride, y2_choff, split_n, M, N, st);
+      if (rc != LFSR_E_ARG) return rc;
+    }
+  }
   RowGemmArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = 1.0f;
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.ln_cols = ln_cols; p.pe = pe; p.pe_stride = pe_stride; p.pe_rows = pe_rows; p.pe_div = pe_div;

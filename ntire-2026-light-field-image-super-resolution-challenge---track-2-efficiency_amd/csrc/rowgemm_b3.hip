@@ -1,4 +1,4 @@
-// Row-streaming GEMM on the bf16 MFMA pipe with fp32 operands carried EXACTLY as three bf16 terms (opt-in: LFSR_ROWGEMM=b3).
+// Row-streaming GEMM on the bf16 MFMA pipe with fp32 operands carried EXACTLY as three bf16 terms (default; LFSR_ROWGEMM=f32 keeps rowgemm.hip's fp32-MFMA kernel).
 //   Y[m, n0:n0+64] = act(X[m, 0:K] W^T) (+res)        -- the transformer linears of EPIT.py:110-128 / LFT.py:188-246 (no bias)
 // x = x0 + x1 + x2 and w = w0 + w1 + w2 by truncation (each term a bf16, the sum exact); the six products of order <= 2 (x0w0, x0w1, x1w0, x1w1, x0w2, x2w0) run as
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the dropped terms are below 2^-24 relative, the dot product is closer to fp64 than an fp32 FMA chain
@@ -22,6 +22,10 @@ struct RowGemmB3Args {
   float* Y; int y_stride; int y_choff;
   long long M; int N;
   float slope;
+  // LN form (as RowGemmArgs in rowgemm.hip): panels n0 < ln_cols see LayerNorm(x (+ pe)), the others the raw rows; panels n0 >= split_n store to Y2
+  const float* ln_g; const float* ln_b; float ln_eps; int ln_cols;
+  const float* pe; int pe_stride; int pe_rows; int pe_div;
+  float* Y2; int y2_stride; int y2_choff; int split_n;
 };
 
 __device__ __forceinline__ unsigned b3_hi_pair(unsigned hi_src, unsigned lo_src) {      // (hi_src's upper half) << 16 | lo_src's upper half
@@ -48,7 +52,7 @@ __device__ __forceinline__ void b3_mfma(f32x4b& c, const u32x4b a, const u32x4b 
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
-template <int K>
+template <int K, bool LN = false>
 __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
   constexpr int NB = 64, BMR = 64;
   constexpr int KS = K / 32;                // K steps
@@ -80,6 +84,8 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)(p.M * p.x_stride * 4), 0x00020000);
   const int offL = ((wave * 16 + l15) * p.x_stride + p.x_choff + 8 * g) * 4;
   float4 xr[KS][2];
+  float4 pr[LN ? KS : 1][2];
+  const bool do_ln = LN && n0 < p.ln_cols;
   auto prefetch = [&](long long tile) {
     const int s4 = (int)(tile * BMR) * p.x_stride * 4;
 #pragma unroll
@@ -89,11 +95,50 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
         const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offL + (32 * s + 4 * e) * 4, s4, 0));
         xr[s][e] = make_float4(v.x, v.y, v.z, v.w);
       }
+    if constexpr (LN) if (do_ln && p.pe) {
+      const int m = (int)(tile * BMR) + wave * 16 + l15;
+      const float* pp = p.pe + (long long)((m / p.pe_div) % p.pe_rows) * p.pe_stride + 8 * g;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) { pr[s][0] = *reinterpret_cast<const float4*>(pp + 32 * s); pr[s][1] = *reinterpret_cast<const float4*>(pp + 32 * s + 4); }
+    }
   };
   long long tile = blockIdx.x;
   if (tile < ntiles) prefetch(tile);
   const unsigned short* wl = swb + l15 * LRH + 8 * g;          // this lane's A-operand slot: weight row l15 (+16 per sub-tile), k-group g
   for (; tile < ntiles; tile += gridDim.x) {
+    if constexpr (LN) if (do_ln) {
+      // nn.LayerNorm(K) of the lane's row: its K values sit in the four lanes (row l15, g = 0..3), 8 KS each -- an in-lane sum and two wave shuffles per pass
+      float sm = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          if (p.pe) { xr[s][e].x += pr[s][e].x; xr[s][e].y += pr[s][e].y; xr[s][e].z += pr[s][e].z; xr[s][e].w += pr[s][e].w; }
+          sm += (xr[s][e].x + xr[s][e].y) + (xr[s][e].z + xr[s][e].w);
+        }
+      sm += __shfl_xor(sm, 16);
+      sm += __shfl_xor(sm, 32);
+      const float mu = sm * (1.0f / K);
+      float q2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          xr[s][e].x -= mu; xr[s][e].y -= mu; xr[s][e].z -= mu; xr[s][e].w -= mu;
+          q2 += (xr[s][e].x * xr[s][e].x + xr[s][e].y * xr[s][e].y) + (xr[s][e].z * xr[s][e].z + xr[s][e].w * xr[s][e].w);
+        }
+      q2 += __shfl_xor(q2, 16);
+      q2 += __shfl_xor(q2, 32);
+      const float rstd = 1.0f / sqrtf(q2 * (1.0f / K) + p.ln_eps);
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float4 gv = *reinterpret_cast<const float4*>(p.ln_g + 32 * s + 8 * g + 4 * e);
+          const float4 bv = *reinterpret_cast<const float4*>(p.ln_b + 32 * s + 8 * g + 4 * e);
+          xr[s][e] = make_float4(xr[s][e].x * rstd * gv.x + bv.x, xr[s][e].y * rstd * gv.y + bv.y, xr[s][e].z * rstd * gv.z + bv.z, xr[s][e].w * rstd * gv.w + bv.w);
+        }
+    }
     u32x4b x0[KS], x1[KS], x2[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) b3_split8(xr[s][0], xr[s][1], x0[s], x1[s], x2[s]);
@@ -101,7 +146,11 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
     f32x4b acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_nop 4");                 // (the split's VALU results feed the asm MFMAs below: the compiler does not see an MFMA there)
+    // the split's VALU results feed the asm MFMAs below and the compiler does not see an MFMA there: the wait states a VALU write needs before an MFMA reads the
+    // register are inserted by hand, TIED to every plane so that the scheduler cannot sink a split instruction behind them (found with the LN form: the first
+    // sub-tile's columns were wrong when the split was scheduled right in front of the first MFMA)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("s_nop 4" : "+v"(x0[s]), "+v"(x1[s]), "+v"(x2[s]));
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -119,9 +168,12 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
         b3_mfma(acc[t], w0, x0[s]);
       }
     }
-    asm volatile("s_nop 15\n\ts_nop 15");      // MFMA results -> VALU reads below (the hazard the compiler would pad for a builtin)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));      // MFMA results -> VALU reads below (the wait the compiler would pad for a builtin), tied to the accumulators
     // epilogue: lane (row l15, g) holds channels n0 + 16 t + 4 g .. + 3 of its row
     const long long m = tile * BMR + wave * 16 + l15;
+    const bool second = p.Y2 && n0 >= p.split_n;        // (block-uniform)
+    float* const Yp = second ? p.Y2 : p.Y;
+    const int ys = second ? p.y2_stride : p.y_stride, yc = second ? p.y2_choff - p.split_n : p.y_choff;
     if (m < p.M) {
       float4 rv[4];
       if (p.R1) {
@@ -139,21 +191,21 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
         if (p.R1) { v[0] += rv[t].x; v[1] += rv[t].y; v[2] += rv[t].z; v[3] += rv[t].w; }
-        *reinterpret_cast<float4*>(p.Y + m * p.y_stride + p.y_choff + n) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(Yp + m * ys + yc + n) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
 }
 
-template <int K>
+template <int K, bool LN = false>
 int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
   constexpr int smem = 3 * 64 * (K + 8) * 2;
-  constexpr int per_cu = smem <= 52 * 1024 ? 3 : 2;
+  constexpr int per_cu = LN ? 2 : (smem <= 52 * 1024 ? 3 : 2);      // (the LN form of K = 128 needs 189 VGPRs: two 256-thread blocks per CU)
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm_b3<K>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm_b3<K, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
@@ -163,7 +215,7 @@ int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
   if (gx > 8) gx &= ~7;
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = (int)ntiles;
-  hipLaunchKernelGGL((k_rowgemm_b3<K>), dim3((unsigned)gx, (unsigned)nby), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((k_rowgemm_b3<K, LN>), dim3((unsigned)gx, (unsigned)nby), dim3(256), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
@@ -182,6 +234,26 @@ int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, con
   switch (K) {
     case 64: return launch_b3<64>(p, st);
     case 128: return launch_b3<128>(p, st);
+    default: return LFSR_E_ARG;
+  }
+}
+
+// LayerNorm + attention in-projection in one launch on the three-term bf16 form (argument meaning as lfsr_rowgemm_ln_launch in rowgemm.hip)
+int lfsr_rowgemm_b3_ln_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* ln_g, const float* ln_b, float ln_eps, int ln_cols,
+                              const float* pe, int pe_stride, int pe_rows, int pe_div, float* y, int y_stride, int y_choff,
+                              float* y2, int y2_stride, int y2_choff, int split_n, long long M, int N, hipStream_t st) {
+  if (!x || !w_packed || !ln_g || !ln_b || !y || M <= 0 || N <= 0 || N % 64 || ln_cols % 64 || (y2 && (split_n % 64 || split_n <= 0 || split_n >= N))) return LFSR_E_ARG;
+  if ((x_stride | x_choff | y_stride | y_choff) & 3 || (y2 && ((y2_stride | y2_choff) & 3)) || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
+  if (x_stride < x_choff + K || y_stride < y_choff + (y2 ? split_n : N) || (y2 && y2_stride < y2_choff + N - split_n)) return LFSR_E_ARG;
+  if (((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)w_packed) & 15) return LFSR_E_ARG;
+  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  RowGemmB3Args p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = 1.0f;
+  p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.ln_cols = ln_cols; p.pe = pe; p.pe_stride = pe_stride; p.pe_rows = pe_rows; p.pe_div = pe_div;
+  p.Y2 = y2; p.y2_stride = y2_stride; p.y2_choff = y2_choff; p.split_n = split_n;
+  switch (K) {
+    case 64: return launch_b3<64, true>(p, st);
+    case 128: return launch_b3<128, true>(p, st);
     default: return LFSR_E_ARG;
   }
 }

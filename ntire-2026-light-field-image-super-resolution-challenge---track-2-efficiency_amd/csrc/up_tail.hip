@@ -463,6 +463,8 @@ __global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) ut_split8(v[s][0], v[s][1], f0[i][s], f1[i][s], f2[i][s]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("s_nop 4" : "+v"(f0[i][s]), "+v"(f1[i][s]), "+v"(f2[i][s]));   // VALU write -> asm MFMA read: wait states by hand, tied to the planes
   }
   store_w(0);
   __syncthreads();

@@ -96,9 +96,13 @@ def test_ffn_with_layernorm_inside(K1, H, M):
 
 
 @pytest.mark.parametrize("K,M,with_pe", [(128, 5003, False), (128, 4096, True), (64, 5003, True), (64, 100, False)])
-def test_linear_with_layernorm_inside(K, M, with_pe, monkeypatch):
-    """q | k from LayerNorm(x + pe), v from x in one launch: the same bits as lfsr_layernorm_fwd + two lfsr_linear_fwd (fp32-MFMA form)"""
-    monkeypatch.setenv("LFSR_ROWGEMM", "f32")
+@pytest.mark.parametrize("form", ["f32", "bf16x3"])
+def test_linear_with_layernorm_inside(K, M, with_pe, form, monkeypatch):
+    """q | k from LayerNorm(x + pe), v from x in one launch against fp64; the fp32-MFMA form returns the same bits as lfsr_layernorm_fwd + two lfsr_linear_fwd"""
+    if form == "f32":
+        monkeypatch.setenv("LFSR_ROWGEMM", "f32")
+    else:
+        monkeypatch.delenv("LFSR_ROWGEMM", raising=False)
     lib = capi.load()
     N, split = 3 * K, 2 * K
     x, w = rnd((M, K), 31) + 2.0 * rnd((M, 1), 32), rnd((N, K), 33, 0.1)
@@ -118,7 +122,7 @@ def test_linear_with_layernorm_inside(K, M, with_pe, monkeypatch):
     ref_n = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * g + b
     assert np.abs(qk.cpu().numpy() - ref_n @ w[:split].astype(np.float64).T).max() < ATOL
     assert np.abs(v.cpu().numpy() - x.astype(np.float64) @ w[split:].astype(np.float64).T).max() < ATOL
-    if M >= 2048:      # (below that lfsr_linear_fwd runs the gather-GEMM, a different summation order)
+    if M >= 2048 and form == "f32":      # (below that lfsr_linear_fwd runs the gather-GEMM, a different summation order)
         qk2, v2 = torch.empty_like(qk), torch.empty_like(v)
         capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xn), K, 0, K, capi.dev_ptr(wp), None, None, 0, 0, capi.dev_ptr(qk2), split, 0, M, split, 1.0, capi.stream_ptr()), "qk")
         capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xd), K, 0, K, capi.dev_ptr(wp[split * K:]), None, None, 0, 0, capi.dev_ptr(v2), N - split, 0, M, N - split, 1.0,
