@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
     // sub-tile's columns were wrong when the split was scheduled right in front of the first MFMA)
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("s_nop 4" : "+v"(x0[s]), "+v"(x1[s]), "+v"(x2[s]));
+    asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));       // (the zeroed accumulators are MFMA sources too)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
