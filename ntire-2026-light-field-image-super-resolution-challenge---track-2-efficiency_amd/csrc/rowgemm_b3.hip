@@ -3,6 +3,8 @@
 // x = x0 + x1 + x2 and w = w0 + w1 + w2 by truncation (each term a bf16, the sum exact); the six products of order <= 2 (x0w0, x0w1, x1w0, x1w1, x0w2, x2w0) run as
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the dropped terms are below 2^-24 relative, the dot product is closer to fp64 than an fp32 FMA chain
 // (tests/test_oracle_vs_golden.py::test_split_bf16_products).  Six K = 32 MFMAs of 17 cycles replace eight 16x16x4 fp32 MFMAs of 32 cycles: 2.5x less matrix-pipe time.
+// Edge semantics: finite inputs only differ from an fp32 FMA chain by rounding; an infinite input yields NaN (inf - inf in the residual) where fp32 would carry the infinity;
+// residual terms below the bf16 denormal range (|x| < 2^-110) are flushed -- both outside anything the models produce.
 // Structure: a persistent 256-thread block keeps the three bf16 planes of its 64 x K weight panel in LDS (split once per block from the packed fp32 weights); each wave
 // owns 16 token rows per tile and loads them straight from global memory in B-operand order (lane = row, eight consecutive k per k-group: two 16-B loads per K step),
 // splits them in registers (5.5 VALU per element) and runs 4 column sub-tiles x 6 products per K step.  No A image in LDS, no barrier in the tile loop.
