@@ -96,7 +96,10 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
   // LayerNorms formed inside the consuming kernel: feed_forward.0 in the fused feed-forward (default: 293 us against 33 + 295 us, 10 launches less per forward);
   // the attention norm inside the q | k | v projection only with LFSR_LN_FUSE=2 -- measured SLOWER (334 us against 33 + 209 us: each of the four q | k column
   // panels repeats the norm of its row tile, and 384 x 128 fp32 weights do not fit one block's LDS); LFSR_LN_FUSE=0: every norm as its own launch
-  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf && lf[0] == '2', no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;
+  const char* rgs = getenv("LFSR_ROWGEMM");
+  const bool rowgemm_f32 = rgs && (rgs[0] == 'f' || rgs[0] == '1');
+  // (late round 2) on the three-term bf16 row-GEMM with 128-column panels the fused attention norm DOES pay (818 -> 831 patches/s): default there; LFSR_LN_FUSE=1 keeps the LayerNorm launch
+  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf ? lf[0] == '2' : !rowgemm_f32, no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;
   // BasicTrans.forward (EPIT.py:110-128) over all sequences of one pass
   auto trans = [&](const float* X, const std::string& e, int vertical, float* Yo) -> int {
     int r;

@@ -122,7 +122,10 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
   const char* lf = getenv("LFSR_LN_FUSE");
   // LayerNorms formed inside the consuming kernel (see epit.cpp): feed_forward.0 inside the fused feed-forward by default; the attention norms inside the
   // q | k | v projection only with LFSR_LN_FUSE=2 (measured slower: 1464 against 143 + 795 us for SpaTrans at 32 patches); LFSR_LN_FUSE=0: all norms as launches
-  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf && lf[0] == '2';
+  const char* rgs = getenv("LFSR_ROWGEMM");
+  const bool rowgemm_f32 = rgs && (rgs[0] == 'f' || rgs[0] == '1');
+  // (late round 2) on the three-term bf16 row-GEMM with 128-column panels the fused attention norms DO pay (1636 -> 1680 patches/s): default there; LFSR_LN_FUSE=1 keeps the LayerNorm launches
+  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf ? lf[0] == '2' : !rowgemm_f32;
   for (int b = 0; b < c->nlayer; ++b) {
     // ---- AngTrans (LFT.py:233-246): tokens = the A*A views at one (y, x); E = 64, 8 heads of 8, no mask -----------
     std::string an = "altblock." + std::to_string(b) + ".ang_trans.";

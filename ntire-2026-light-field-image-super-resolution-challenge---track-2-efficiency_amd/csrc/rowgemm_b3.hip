@@ -54,9 +54,11 @@ __device__ __forceinline__ void b3_mfma(f32x4b& c, const u32x4b a, const u32x4b 
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
-template <int K, bool LN = false>
-__global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
-  constexpr int NB = 64, BMR = 64;
+// NB = 64: 256 threads (4 waves x 16 rows), up to three blocks per CU; NB = 128: 512 threads (8 waves x 16 rows), one block per CU -- the token rows are read and split
+// once per 128 output columns instead of once per 64 (there is no barrier in the tile loop, so eight waves of one block overlap as well as four waves of two)
+template <int K, bool LN = false, int NB = 64>
+__global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
+  constexpr int NTH = NB * 4, BMR = NB, NT = NB / 16;
   constexpr int KS = K / 32;                // K steps
   constexpr int LRH = K + 8;                // LDS row stride in bf16 (2 K + 16 bytes: 16 consecutive rows start in distinct 16-B slots)
   constexpr int PLANE = NB * LRH;           // bf16 per plane
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
   const long long ntiles = (p.M + BMR - 1) / BMR;
 
   // the block's weight panel: split into planes, 8 consecutive k per thread-iteration
-  for (int i = tid; i < NB * (K / 8); i += 256) {
+  for (int i = tid; i < NB * (K / 8); i += NTH) {
     const int r = i / (K / 8), c = i - r * (K / 8);
     const bool ok = n0 + r < p.N;
     const float* src = p.Wp + (long long)(ok ? n0 + r : 0) * K + c * 8;
@@ -145,19 +147,20 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) b3_split8(xr[s][0], xr[s][1], x0[s], x1[s], x2[s]);
     if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
-    f32x4b acc[4];
+    f32x4b acc[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
     // the split's VALU results feed the asm MFMAs below and the compiler does not see an MFMA there: the wait states a VALU write needs before an MFMA reads the
     // register are inserted by hand, TIED to every plane so that the scheduler cannot sink a split instruction behind them (found with the LN form: the first
     // sub-tile's columns were wrong when the split was scheduled right in front of the first MFMA)
 #pragma unroll
     for (int s = 0; s < KS; ++s) asm volatile("s_nop 4" : "+v"(x0[s]), "+v"(x1[s]), "+v"(x2[s]));
-    asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));       // (the zeroed accumulators are MFMA sources too)
+#pragma unroll
+    for (int t = 0; t < NT; t += 4) asm volatile("s_nop 1" : "+v"(acc[t]), "+v"(acc[t + 1]), "+v"(acc[t + 2]), "+v"(acc[t + 3]));       // (the zeroed accumulators are MFMA sources too)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const unsigned short* wq = wl + t * 16 * LRH + 32 * s;
         const u32x4b w0 = *reinterpret_cast<const u32x4b*>(wq);
         const u32x4b w1 = *reinterpret_cast<const u32x4b*>(wq + PLANE);
@@ -171,23 +174,25 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
         b3_mfma(acc[t], w0, x0[s]);
       }
     }
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));      // MFMA results -> VALU reads below (the wait the compiler would pad for a builtin), tied to the accumulators
+#pragma unroll
+    for (int t = 0; t < NT; t += 4)      // MFMA results -> VALU reads below (the wait the compiler would pad for a builtin), tied to the accumulators
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[t]), "+v"(acc[t + 1]), "+v"(acc[t + 2]), "+v"(acc[t + 3]));
     // epilogue: lane (row l15, g) holds channels n0 + 16 t + 4 g .. + 3 of its row
     const long long m = tile * BMR + wave * 16 + l15;
     const bool second = p.Y2 && n0 >= p.split_n;        // (block-uniform)
     float* const Yp = second ? p.Y2 : p.Y;
     const int ys = second ? p.y2_stride : p.y_stride, yc = second ? p.y2_choff - p.split_n : p.y_choff;
     if (m < p.M) {
-      float4 rv[4];
+      float4 rv[NT];
       if (p.R1) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NT; ++t) {
           const int n = n0 + 16 * t + 4 * g;
           rv[t] = n + 3 < p.N ? *reinterpret_cast<const float4*>(p.R1 + m * p.r1_stride + p.r1_choff + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int n = n0 + 16 * t + 4 * g;
         if (n + 3 >= p.N) continue;
         float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
@@ -200,25 +205,25 @@ __global__ __launch_bounds__(256) void k_rowgemm_b3(RowGemmB3Args p) {
   }
 }
 
-template <int K, bool LN = false>
+template <int K, bool LN = false, int NB = 64>
 int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
-  constexpr int smem = 3 * 64 * (K + 8) * 2;
-  constexpr int per_cu = LN ? 2 : (smem <= 52 * 1024 ? 3 : 2);      // (the LN form of K = 128 needs 189 VGPRs: two 256-thread blocks per CU)
+  constexpr int smem = 3 * NB * (K + 8) * 2;
+  constexpr int per_cu = NB == 128 ? 1 : LN ? 2 : (smem <= 52 * 1024 ? 3 : 2);      // (the LN form of K = 128 needs 189 VGPRs: two 256-thread blocks per CU)
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm_b3<K, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm_b3<K, LN, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
-  const long long ntiles = (p.M + 63) / 64;
-  const int nby = (p.N + 63) / 64;
+  const long long ntiles = (p.M + NB - 1) / NB;
+  const int nby = (p.N + NB - 1) / NB;
   int gx = 256 * per_cu / nby;
   if (gx > 8) gx &= ~7;
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = (int)ntiles;
-  hipLaunchKernelGGL((k_rowgemm_b3<K, LN>), dim3((unsigned)gx, (unsigned)nby), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((k_rowgemm_b3<K, LN, NB>), dim3((unsigned)gx, (unsigned)nby), dim3(NB * 4), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
@@ -234,9 +239,11 @@ int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, con
   RowGemmB3Args p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = slope;
+  const char* nsel = getenv("LFSR_B3_NB");       // "128": 128-column panels where N allows (A/B runs: EPIT 818 -> 800, LFT 1636 -> 1646 patches/s; not the default)
+  const bool wide = nsel && nsel[0] == '1' && N % 128 == 0;
   switch (K) {
-    case 64: return launch_b3<64>(p, st);
-    case 128: return launch_b3<128>(p, st);
+    case 64: return wide ? launch_b3<64, false, 128>(p, st) : launch_b3<64>(p, st);
+    case 128: return wide ? launch_b3<128, false, 128>(p, st) : launch_b3<128>(p, st);
     default: return LFSR_E_ARG;
   }
 }
@@ -254,9 +261,12 @@ int lfsr_rowgemm_b3_ln_launch(const float* x, int x_stride, int x_choff, int K, 
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = 1.0f;
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.ln_cols = ln_cols; p.pe = pe; p.pe_stride = pe_stride; p.pe_rows = pe_rows; p.pe_div = pe_div;
   p.Y2 = y2; p.y2_stride = y2_stride; p.y2_choff = y2_choff; p.split_n = split_n;
+  // 128-column panels by default here (the norm and the split are repeated per panel: EPIT 818 -> 831, LFT 1636 -> 1680 patches/s with them; LFSR_B3_NB=64: 64-column panels)
+  const char* nsel = getenv("LFSR_B3_NB");
+  const bool wide = !(nsel && nsel[0] == '6') && ln_cols % 128 == 0 && (!y2 || split_n % 128 == 0);
   switch (K) {
-    case 64: return launch_b3<64, true>(p, st);
-    case 128: return launch_b3<128, true>(p, st);
+    case 64: return wide ? launch_b3<64, true, 128>(p, st) : launch_b3<64, true>(p, st);
+    case 128: return wide ? launch_b3<128, true, 128>(p, st) : launch_b3<128, true>(p, st);
     default: return LFSR_E_ARG;
   }
 }
