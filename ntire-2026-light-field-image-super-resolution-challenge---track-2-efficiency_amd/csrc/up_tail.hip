@@ -412,12 +412,11 @@ __global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
   constexpr int S2 = S * S, CC = 64 / S2, NCH = 64 / CC;
   constexpr int CPT = CC / 4;
   constexpr int PW = UT_X + 2;
-  constexpr int WRH = 72;                             // bf16 per weight row in LDS (64 + 8: 16 consecutive rows start in distinct 16-B slots)
-  constexpr int WPL = 64 * WRH;                       // bf16 per weight plane
+  constexpr int WPL = 64 * 64;                        // bf16 per weight plane: [K step s][k-group g][row n][8] -- the conflict-free image of rowgemm_b3.hip
   extern __shared__ __attribute__((aligned(16))) float smu[];
   float* sU = smu;                                    // [UT2_ROWS][LDS_ROW]   U chunk, column n = dc*S2 + ij
   float* sW3 = sU + UT2_ROWS * LDS_ROW;               // [64][9]
-  unsigned short* sWb = reinterpret_cast<unsigned short*>(sW3 + 64 * 9);   // [2][3][64][WRH]
+  unsigned short* sWb = reinterpret_cast<unsigned short*>(sW3 + 64 * 9);   // [2][3 planes][8 (K step, k-group)][64 rows][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int Hm = p.A * p.h, Wm = p.A * p.w, HW = p.h * p.w;
@@ -436,7 +435,7 @@ __global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
   auto store_w = [&](int bufi) {
     u32x4u p0, p1, p2;
     ut_split8(rw[0], rw[1], p0, p1, p2);
-    unsigned short* d = sWb + bufi * 3 * WPL + wr * WRH + wk * 8;
+    unsigned short* d = sWb + bufi * 3 * WPL + (wk * 64 + wr) * 8;       // wk = 4 s + g
     *reinterpret_cast<u32x4u*>(d) = p0; *reinterpret_cast<u32x4u*>(d + WPL) = p1; *reinterpret_cast<u32x4u*>(d + 2 * WPL) = p2;
   };
   fetch_w(0);
@@ -490,12 +489,12 @@ __global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
           const int ct = 2 * ch + c2;
           f32x4u acc = {0.f, 0.f, 0.f, 0.f};
           asm volatile("s_nop 1" : "+v"(acc));
-          const unsigned short* wq = sWc + (ct * 16 + l15) * WRH + 8 * g;
+          const unsigned short* wq = sWc + (g * 64 + ct * 16 + l15) * 8;
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            const u32x4u w0 = *reinterpret_cast<const u32x4u*>(wq + 32 * s);
-            const u32x4u w1 = *reinterpret_cast<const u32x4u*>(wq + 32 * s + WPL);
-            const u32x4u w2 = *reinterpret_cast<const u32x4u*>(wq + 32 * s + 2 * WPL);
+            const u32x4u w0 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s);
+            const u32x4u w1 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s + WPL);
+            const u32x4u w2 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s + 2 * WPL);
             ut_mfma(acc, w2, f0[i][s]); ut_mfma(acc, w0, f2[i][s]); ut_mfma(acc, w1, f1[i][s]);
             ut_mfma(acc, w1, f0[i][s]); ut_mfma(acc, w0, f1[i][s]); ut_mfma(acc, w0, f0[i][s]);
           }
@@ -574,7 +573,7 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
   if (grid > 0x7fffffffLL) return LFSR_E_ARG;
   const char* usel = getenv("LFSR_UPTAIL");         // "v1" / "v2": the first / second (fp32-MFMA) forms (A/B runs)
   if (!(usel && usel[0] == 'v')) {
-    const int smem3 = (UT2_ROWS * LDS_ROW + 64 * 9) * 4 + 2 * 3 * 64 * 72 * 2;
+    const int smem3 = (UT2_ROWS * LDS_ROW + 64 * 9) * 4 + 2 * 3 * 64 * 64 * 2;
     static std::atomic<bool> attr3_set[64];
     if (!attr3_set[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail3<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem3);
