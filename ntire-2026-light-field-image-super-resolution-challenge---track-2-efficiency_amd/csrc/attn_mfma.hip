@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
         f32x4a pw;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pw[r] = exp2f(S[kt][r] - m);     // exp2(-inf) = 0 on masked keys; an empty band gives NaN exactly like softmax over an all -inf row
+          pw[r] = __builtin_amdgcn_exp2f(S[kt][r] - m);     // raw v_exp_f32 (the argument is <= 0: no range handling needed; results below 2^-126 flush to 0).  exp2(-inf) = 0 on masked keys; an empty band gives NaN exactly like softmax over an all -inf row
           den += pw[r];
         }
         int col = kt * 16 + 4 * g + 4 * l15;
