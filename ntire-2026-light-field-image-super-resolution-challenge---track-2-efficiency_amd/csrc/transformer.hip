@@ -60,6 +60,7 @@ struct AttnArgs {
   int l1, r1, l2, r2;                           // key window [t-l, t+r) per dim, clipped to the grid
   int clip2;                                    // upper clip of dim 2 (LFT.py:168 clamps the column window with h, not w)
   float scale;
+  float scale2;                                 // scale * log2(e): the LDS-tiled kernels run their softmax in base 2
   long long total;                              // nseq * n1 * n2 * nheads
 };
 
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, in
 #pragma unroll
       for (int i = 0; i < HD / 4; ++i) {
         float4 v = qp[i];
-        q[4 * i] = v.x * p.scale; q[4 * i + 1] = v.y * p.scale; q[4 * i + 2] = v.z * p.scale; q[4 * i + 3] = v.w * p.scale;
+        q[4 * i] = v.x * p.scale2; q[4 * i + 1] = v.y * p.scale2; q[4 * i + 2] = v.z * p.scale2; q[4 * i + 3] = v.w * p.scale2;
       }
     }
 #pragma unroll
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, in
           s = fmaf(q[4 * i], kv.x, s); s = fmaf(q[4 * i + 1], kv.y, s); s = fmaf(q[4 * i + 2], kv.z, s); s = fmaf(q[4 * i + 3], kv.w, s);
         }
         const float mn = fmaxf(mx, s);
-        const float corr = expf(mx - mn);
-        const float pw = expf(s - mn);
+        const float corr = __builtin_amdgcn_exp2f(mx - mn);   // base-2 softmax (q carries log2 e): raw v_exp_f32, arguments <= 0, exp2(-inf) = 0 on the first key
+        const float pw = __builtin_amdgcn_exp2f(s - mn);
         den = den * corr + pw;
 #pragma unroll
         for (int i = 0; i < HD / 4; ++i) {
@@ -323,6 +324,7 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
   p.nheads = nheads; p.ns0 = ns0; p.ns1 = ns1; p.ns2 = ns2; p.bs0 = bs0; p.bs1 = bs1; p.bs2 = bs2;
   p.n1 = n1; p.n2 = n2; p.st1 = st1; p.st2 = st2; p.l1 = l1; p.r1 = r1; p.l2 = l2; p.r2 = r2; p.clip2 = clip2 > 0 ? clip2 : n2;
   p.scale = 1.0f / sqrtf((float)hd);
+  p.scale2 = p.scale * 1.44269504088896340736f;
   p.total = (long long)ns0 * ns1 * ns2 * n1 * n2 * nheads;
   // EPI geometry (every angular position visible, <= 160 tokens per sequence, heads of 16): QK^T / softmax / PV on the matrix pipe
   // (attn_mfma.hip); LFSR_ATTN=valu keeps the VALU kernels below (A/B runs)
