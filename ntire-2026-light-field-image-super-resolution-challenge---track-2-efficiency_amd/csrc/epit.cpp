@@ -8,6 +8,7 @@
 struct lfsr_epit {
   int A, s, nblk;
   LfsrParamTable P;
+  std::vector<size_t> ffn_split;      // per block: offset (floats) of the feed-forward weights' pre-split bf16 image in the packed buffer (ffn_b3.hip)
   bool finalized = false;
 };
 
@@ -34,6 +35,7 @@ int lfsr_epit_create(lfsr_epit** out, int A, int scale, int n_block, int channel
     P.add(e + "feed_forward.4.weight", 128, 256, 1);
     P.add(e + "linear_out.weight", 64, 128, 1);
     for (int i : {0, 2, 4}) P.add(p + "conv." + std::to_string(i) + ".weight", 64, 64, 9);
+    c->ffn_split.push_back(P.reserve((lfsr_ffn_b3_presplit_bytes(128, 256, 128) + 3) / 4));
   }
   P.add("upsampling.0.weight", 64 * scale * scale, 64, 1, 1, 64);   // PixelShuffle order folded into the packing
   P.add("upsampling.3.weight", 1, 64, 9, 0, 0, true);
@@ -50,8 +52,13 @@ int lfsr_epit_load_param(lfsr_epit* c, const char* key, const float* data, size_
   return c->P.load(key, data, numel, stream);
 }
 int lfsr_epit_finalize(lfsr_epit* c, void* stream) {
-  (void)stream;
   if (!c || !c->P.packed || !c->P.all_loaded()) return LFSR_E_ARG;
+  // the feed-forward weights of every block, split once into their three bf16 planes in the fused kernel's LDS chunk order
+  for (int b = 0; b < c->nblk; ++b) {
+    const std::string e = "altblock." + std::to_string(b) + ".epi_trans.";
+    const int rc = lfsr_ffn_b3_presplit(c->P.w(e + "feed_forward.1.weight"), c->P.w(e + "feed_forward.4.weight"), 128, 256, 128, c->P.packed + c->ffn_split[b], lfsr_stream(stream));
+    if (rc) return rc;
+  }
   c->finalized = true;
   return LFSR_OK;
 }
@@ -101,7 +108,9 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
   // (late round 2) on the three-term bf16 row-GEMM with 128-column panels the fused attention norm DOES pay (818 -> 831 patches/s): default there; LFSR_LN_FUSE=1 keeps the LayerNorm launch
   const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf ? lf[0] == '2' : !rowgemm_f32, no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;
   // BasicTrans.forward (EPIT.py:110-128) over all sequences of one pass
-  auto trans = [&](const float* X, const std::string& e, int vertical, float* Yo) -> int {
+  const char* psel = getenv("LFSR_FFN_PRESPLIT");
+  const bool presplit = !(psel && psel[0] == '0');      // LFSR_FFN_PRESPLIT=0: the kernel splits the weight chunks itself (A/B runs)
+  auto trans = [&](const float* X, const std::string& e, int vertical, float* Yo, int blk) -> int {
     int r;
     if ((r = lfsr_linear_fwd(X, 64, 0, 64, P.w(e + "linear_in.weight"), nullptr, nullptr, 0, 0, T, 128, 0, npix, 128, 1.0f, stream))) return r;
     const float* Win = P.w(e + "attention.in_proj_weight");
@@ -124,7 +133,7 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
     if ((r = lfsr_linear_fwd(TN, 128, 0, 128, P.w(e + "attention.out_proj.weight"), nullptr, T, 128, 0, T2, 128, 0, npix, 128, 1.0f, stream))) return r;
     const float *fg = P.w(e + "feed_forward.0.weight"), *fb = P.w(e + "feed_forward.0.bias");
     r = (ln_fuse && !no_ffn_fused) ? lfsr_ffn_ln_launch(T2, 128, 0, fg, fb, 1e-5f, P.w(e + "feed_forward.1.weight"), P.w(e + "feed_forward.4.weight"), T2, 128, 0, T, 128, 0,
-                                                        npix, 128, 256, 128, 0.0f, lfsr_stream(stream))
+                                                        npix, 128, 256, 128, 0.0f, lfsr_stream(stream), presplit ? P.packed + c->ffn_split[blk] : nullptr)
                                    : LFSR_E_ARG;
     if (r == LFSR_E_ARG) {
       if ((r = lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, fg, fb, V, 128, 0, npix, 128, 1e-5f, stream))) return r;
@@ -150,7 +159,7 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
     const bool last = b == c->nblk - 1;
     for (int vert = 0; vert < 2; ++vert) {
       const float* in = vert ? MID : cur;
-      RC(trans(in, p + "epi_trans.", vert, Y));
+      RC(trans(in, p + "epi_trans.", vert, Y, b));
       RC(conv(Y, p + "conv.0.weight", C1, nullptr, nullptr, L));
       RC(conv(C1, p + "conv.2.weight", C2, nullptr, nullptr, L));
       // + shortcut (the block INPUT both times, EPIT.py:153,159); the network-level skip (:66) rides on the very last conv

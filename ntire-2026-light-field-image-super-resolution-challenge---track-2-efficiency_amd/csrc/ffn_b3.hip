@@ -27,6 +27,7 @@ struct FfnB3Args {
   int x_bytes, y_bytes, r_bytes;
   float slope;
   const float* ln_g; const float* ln_b; float ln_eps;
+  const unsigned short* Wsplit;                 // non-null: the chunks' LDS images (three planes of W1 and W2 per chunk, operand order) made once by k_ffn_presplit
 };
 
 __device__ __forceinline__ unsigned c3_hi_pair(unsigned hi_src, unsigned lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
@@ -49,7 +50,7 @@ __device__ __forceinline__ void c3_mfma(f32x16c& c, const u32x4c a, const u32x4c
 // MFMA results -> VALU reads: the wait the compiler would insert for a builtin (tied to the accumulator so it stays between the two)
 __device__ __forceinline__ void c3_settle(f32x16c& c) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c)); }
 
-template <int K1, int N2>
+template <int K1, int N2, bool PRE>
 __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
   constexpr int KS1 = K1 / 16, NT2 = N2 / 32;
   constexpr int R1H = K1 + 8, R2H = 40;                          // LDS row strides in bf16: rows start in distinct 16-B slots over 16 consecutive rows
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
   if (rounds == 0) return;
 
   // weight chunk c: fetched as fp32 into registers at the start of a chunk, split and stored into the other buffer at its end
-  float4 w1r[W1L][2], w2r[W2L][2];
+  float4 w1r[PRE ? 1 : W1L][2], w2r[PRE ? 1 : W2L][2];
   auto fetch_chunk = [&](int c) {
+    if constexpr (!PRE) {
 #pragma unroll
     for (int i = 0; i < W1L; ++i) {
       const int idx = tid + 512 * i;
@@ -92,8 +94,10 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
         w2r[i][0] = *reinterpret_cast<const float4*>(src); w2r[i][1] = *reinterpret_cast<const float4*>(src + 4);
       }
     }
+    }
   };
   auto store_chunk = [&](unsigned short* buf) {
+    if constexpr (!PRE) {
 #pragma unroll
     for (int i = 0; i < W1L; ++i) {
       const int idx = tid + 512 * i;
@@ -123,10 +127,33 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
         *reinterpret_cast<u32x2c*>(d + 2 * P2) = u32x2c{p2.x, p2.y}; *reinterpret_cast<u32x2c*>(d + 2 * P2 + 8) = u32x2c{p2.z, p2.w};
       }
     }
+    }
   };
 
-  fetch_chunk(0);
-  store_chunk(sw);
+  // pre-split form: a chunk's LDS image is copied as it stands, 16 B per thread and piece, in two halves so that no more than four pieces are in flight
+  // (the first half is stored after GEMM 1, the second at the chunk's end; the image of chunk c starts at c * BUFH)
+  constexpr int IMG16 = BUFH / 8;                    // 16-B pieces per chunk image
+  constexpr int NQ = (IMG16 + 511) / 512, NQH = (NQ + 1) / 2;
+  u32x4c vq[PRE ? NQH : 1];
+  constexpr bool pre = PRE;
+  auto fetch_img = [&](int c, int half_i) {
+    if constexpr (PRE)
+#pragma unroll
+    for (int i = 0; i < NQH; ++i) {
+      const int piece = tid + 512 * (half_i * NQH + i);
+      if (half_i * NQH + i < NQ && piece < IMG16) vq[i] = *reinterpret_cast<const u32x4c*>(p.Wsplit + ((long long)c * IMG16 + piece) * 8);
+    }
+  };
+  auto store_img = [&](unsigned short* buf, int half_i) {
+    if constexpr (PRE)
+#pragma unroll
+    for (int i = 0; i < NQH; ++i) {
+      const int piece = tid + 512 * (half_i * NQH + i);
+      if (half_i * NQH + i < NQ && piece < IMG16) *reinterpret_cast<u32x4c*>(buf + piece * 8) = vq[i];
+    }
+  };
+  if (pre) { fetch_img(0, 0); store_img(sw, 0); fetch_img(0, 1); store_img(sw, 1); }
+  else { fetch_chunk(0); store_chunk(sw); }
   __syncthreads();
 
   typedef float f32x4g __attribute__((ext_vector_type(4)));
@@ -190,7 +217,9 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
     for (int c = 0; c < nch; ++c, ++step) {
       const unsigned short* buf = sw + (step & 1) * BUFH;
       const bool last_step = rd == rounds - 1 && c == nch - 1;
-      if (!last_step) fetch_chunk(c + 1 < nch ? c + 1 : 0);   // flies under this chunk's MFMAs
+      const int cn = c + 1 < nch ? c + 1 : 0;
+      unsigned short* const bufn = sw + ((step + 1) & 1) * BUFH;
+      if (!last_step) { if (pre) fetch_img(cn, 0); else fetch_chunk(cn); }   // flies under this chunk's MFMAs
       if (active) {
         // GEMM 1 (transposed): h[hidden][row], A = W1 rows of the chunk (lane = hidden unit l31, k-group half), B = the token planes
         f32x16c h;
@@ -207,6 +236,7 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
           c3_mfma(h, w1, x0[s]); c3_mfma(h, w0, x1[s]); c3_mfma(h, w0, x0[s]);
         }
         c3_settle(h);
+        if (pre && !last_step) { store_img(bufn, 0); fetch_img(cn, 1); }      // (wave-uniform; every wave of the block passes here or in the branch below)
         // activation + split in place: registers 8 ks .. 8 ks + 7 of the lane = hidden units 16 ks + 8 e + 4 half + r = the eight k slots of GEMM 2's step ks
         u32x4c h0[2], h1[2], h2[2];
 #pragma unroll
@@ -232,7 +262,10 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
           }
         }
       }
-      if (!last_step) store_chunk(sw + ((step + 1) & 1) * BUFH);
+      if (!last_step) {
+        if (pre) { if (!active) { store_img(bufn, 0); fetch_img(cn, 1); } store_img(bufn, 1); }
+        else store_chunk(bufn);
+      }
       __syncthreads();
     }
     // epilogue: lane (row l31, half) holds channels 32 t + 8 q + 4 half + r of its row: 16-B residual loads and stores through buffer descriptors
@@ -259,7 +292,41 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
   }
 }
 
+// one block per chunk: the chunk's LDS image (as store_chunk builds it) written to global memory once per weight set
 template <int K1, int N2>
+__global__ __launch_bounds__(512) void k_ffn_presplit(const float* __restrict__ W1, const float* __restrict__ W2, int H, unsigned short* __restrict__ out) {
+  constexpr int R1H = K1 + 8, R2H = 40, P1 = 32 * R1H, P2 = N2 * R2H, BUFH = 3 * (P1 + P2);
+  constexpr int W1G = 32 * K1 / 8, W2G = N2 * 4;
+  const int c = blockIdx.x, tid = threadIdx.x;
+  unsigned short* buf = out + (long long)c * BUFH;
+  for (int i = tid; i < BUFH / 8; i += 512) *reinterpret_cast<u32x4c*>(buf + i * 8) = u32x4c{0u, 0u, 0u, 0u};    // (padding halves defined)
+  __syncthreads();
+  for (int idx = tid; idx < W1G; idx += 512) {
+    const int r = idx / (K1 / 8), q = idx - r * (K1 / 8);
+    const float* src = W1 + ((long long)c * 32 + r) * K1 + q * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u32x4c p0, p1, p2;
+    c3_split8(a, p0, p1, p2);
+    unsigned short* d = buf + r * R1H + q * 8;
+    *reinterpret_cast<u32x4c*>(d) = p0; *reinterpret_cast<u32x4c*>(d + P1) = p1; *reinterpret_cast<u32x4c*>(d + 2 * P1) = p2;
+  }
+  for (int idx = tid; idx < W2G; idx += 512) {
+    const int n = idx >> 2, q = idx & 3, ks = q >> 1, e = q & 1;
+    const float* src = W2 + (long long)n * H + c * 32 + q * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+    const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u32x4c p0, p1, p2;
+    c3_split8(a, p0, p1, p2);
+    unsigned short* d = buf + 3 * P1 + n * R2H + 16 * ks + 4 * e;
+    typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2c*>(d) = u32x2c{p0.x, p0.y};          *reinterpret_cast<u32x2c*>(d + 8) = u32x2c{p0.z, p0.w};
+    *reinterpret_cast<u32x2c*>(d + P2) = u32x2c{p1.x, p1.y};     *reinterpret_cast<u32x2c*>(d + P2 + 8) = u32x2c{p1.z, p1.w};
+    *reinterpret_cast<u32x2c*>(d + 2 * P2) = u32x2c{p2.x, p2.y}; *reinterpret_cast<u32x2c*>(d + 2 * P2 + 8) = u32x2c{p2.z, p2.w};
+  }
+}
+
+template <int K1, int N2, bool PRE>
 int launch_ffn_b3(const FfnB3Args& p, hipStream_t st) {
   constexpr int smem = 2 * 3 * (32 * (K1 + 8) + N2 * 40) * 2;
   static std::atomic<bool> attr_set[64];
@@ -267,7 +334,7 @@ int launch_ffn_b3(const FfnB3Args& p, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_b3<K1, N2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_b3<K1, N2, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     int v = 0;
     cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
@@ -276,7 +343,7 @@ int launch_ffn_b3(const FfnB3Args& p, hipStream_t st) {
   const long long groups = (p.M + 31) / 32;
   long long grid = cus[dev];
   if (grid > (groups + 7) / 8) grid = (groups + 7) / 8;
-  hipLaunchKernelGGL((k_ffn_b3<K1, N2>), dim3((unsigned)grid), dim3(512), smem, st, p);
+  hipLaunchKernelGGL((k_ffn_b3<K1, N2, PRE>), dim3((unsigned)grid), dim3(512), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
@@ -286,8 +353,8 @@ int launch_ffn_b3(const FfnB3Args& p, hipStream_t st) {
 // LFSR_E_ARG = shape not covered (the caller runs the fp32-MFMA kernel)
 int lfsr_ffn_b3_launch(const float* x, int x_stride, int x_choff, const float* ln_g, const float* ln_b, float ln_eps, const float* w1_packed, const float* w2_packed,
                        const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
-                       long long M, int K1, int H, int N2, float slope, hipStream_t st) {
-  if (!x || !w1_packed || !w2_packed || !y || M <= 0 || H <= 0 || H % 32) return LFSR_E_ARG;
+                       long long M, int K1, int H, int N2, float slope, hipStream_t st, const void* wsplit) {
+  if (!x || !w1_packed || !w2_packed || !y || M <= 0 || H <= 0 || H % 32 || ((uintptr_t)wsplit & 15)) return LFSR_E_ARG;
   if ((x_stride | x_choff | y_stride | y_choff) & 3 || (res && ((res_stride | res_choff) & 3))) return LFSR_E_ARG;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) return LFSR_E_ARG;
   if (x_stride < x_choff + K1 || y_stride < y_choff + N2 || (res && res_stride < res_choff + N2)) return LFSR_E_ARG;
@@ -296,9 +363,24 @@ int lfsr_ffn_b3_launch(const float* x, int x_stride, int x_choff, const float* l
   FfnB3Args p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.W1 = w1_packed; p.W2 = w2_packed;
   p.R = res; p.r_stride = res_stride; p.r_choff = res_choff; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
-  p.M = M; p.H = H; p.slope = slope; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps;
+  p.M = M; p.H = H; p.slope = slope; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.Wsplit = (const unsigned short*)wsplit;
   p.x_bytes = (int)(M * x_stride * 4); p.y_bytes = (int)(M * y_stride * 4); p.r_bytes = res ? (int)(M * res_stride * 4) : 0;
-  if (K1 == 128 && N2 == 128) return launch_ffn_b3<128, 128>(p, st);
-  if (K1 == 64 && N2 == 64) return launch_ffn_b3<64, 64>(p, st);
+  if (K1 == 128 && N2 == 128) return wsplit ? launch_ffn_b3<128, 128, true>(p, st) : launch_ffn_b3<128, 128, false>(p, st);
+  if (K1 == 64 && N2 == 64) return wsplit ? launch_ffn_b3<64, 64, true>(p, st) : launch_ffn_b3<64, 64, false>(p, st);
   return LFSR_E_ARG;
+}
+
+// bytes of / fill the pre-split weight image of one feed-forward block (0 / LFSR_E_ARG: shape not covered)
+size_t lfsr_ffn_b3_presplit_bytes(int K1, int H, int N2) {
+  if (H <= 0 || H % 32) return 0;
+  if (K1 == 128 && N2 == 128) return (size_t)(H / 32) * 3 * (32 * (128 + 8) + 128 * 40) * 2;
+  if (K1 == 64 && N2 == 64) return (size_t)(H / 32) * 3 * (32 * (64 + 8) + 64 * 40) * 2;
+  return 0;
+}
+int lfsr_ffn_b3_presplit(const float* w1_packed, const float* w2_packed, int K1, int H, int N2, void* out, hipStream_t st) {
+  if (!w1_packed || !w2_packed || !out || ((uintptr_t)out & 15) || !lfsr_ffn_b3_presplit_bytes(K1, H, N2)) return LFSR_E_ARG;
+  if (K1 == 128) hipLaunchKernelGGL((k_ffn_presplit<128, 128>), dim3((unsigned)(H / 32)), dim3(512), 0, st, w1_packed, w2_packed, H, (unsigned short*)out);
+  else hipLaunchKernelGGL((k_ffn_presplit<64, 64>), dim3((unsigned)(H / 32)), dim3(512), 0, st, w1_packed, w2_packed, H, (unsigned short*)out);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
 }

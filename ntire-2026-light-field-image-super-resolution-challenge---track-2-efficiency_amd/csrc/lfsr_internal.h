@@ -125,11 +125,13 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
 // ffn_fused.hip: feed-forward block with the LayerNorm in front of it formed in registers (ln_g / ln_b null: x is already normalised)
 int lfsr_ffn_ln_launch(const float* x, int x_stride, int x_choff, const float* ln_g, const float* ln_b, float ln_eps, const float* w1_packed, const float* w2_packed,
                        const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
-                       long long M, int K1, int H, int N2, float slope, hipStream_t st);
+                       long long M, int K1, int H, int N2, float slope, hipStream_t st, const void* wsplit = nullptr);   // wsplit: the weights' pre-split image (lfsr_ffn_b3_presplit), optional
 
 int lfsr_ffn_b3_launch(const float* x, int x_stride, int x_choff, const float* ln_g, const float* ln_b, float ln_eps, const float* w1_packed, const float* w2_packed,
                        const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
-                       long long M, int K1, int H, int N2, float slope, hipStream_t st);
+                       long long M, int K1, int H, int N2, float slope, hipStream_t st, const void* wsplit = nullptr);
+size_t lfsr_ffn_b3_presplit_bytes(int K1, int H, int N2);
+int lfsr_ffn_b3_presplit(const float* w1_packed, const float* w2_packed, int K1, int H, int N2, void* out, hipStream_t st);
 
 // attn_mfma.hip: EPI attention on MFMA; LFSR_E_ARG = geometry not covered
 int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,

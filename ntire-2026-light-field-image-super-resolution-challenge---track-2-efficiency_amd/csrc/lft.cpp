@@ -9,6 +9,7 @@
 struct lfsr_lft {
   int A, s, nlayer;
   LfsrParamTable P;
+  std::vector<size_t> ffn_split_spa, ffn_split_ang;   // per layer: offsets (floats) of the feed-forward weights' pre-split bf16 images (ffn_b3.hip)
   bool finalized = false;
 };
 
@@ -44,6 +45,8 @@ int lfsr_lft_create(lfsr_lft** out, int A, int scale, int n_layer, int channels)
     P.add(an + "feed_forward.0.bias", 64, 1, 1, 0, 0, true);
     P.add(an + "feed_forward.1.weight", 128, 64, 1);
     P.add(an + "feed_forward.4.weight", 64, 128, 1);
+    c->ffn_split_spa.push_back(P.reserve((lfsr_ffn_b3_presplit_bytes(128, 256, 128) + 3) / 4));
+    c->ffn_split_ang.push_back(P.reserve((lfsr_ffn_b3_presplit_bytes(64, 128, 64) + 3) / 4));
   }
   P.add("upsampling.0.weight", 64 * scale * scale, 64, 1, 1, 64);
   P.add("upsampling.3.weight", 1, 64, 9, 0, 0, true);
@@ -66,8 +69,13 @@ int lfsr_lft_load_param(lfsr_lft* c, const char* key, const float* data, size_t 
   return rc;
 }
 int lfsr_lft_finalize(lfsr_lft* c, void* stream) {
-  (void)stream;
   if (!c || !c->P.packed || !c->P.all_loaded()) return LFSR_E_ARG;
+  for (int b = 0; b < c->nlayer; ++b) {      // feed-forward weights split once into the fused kernel's bf16 chunk images
+    const std::string sp = "altblock." + std::to_string(b) + ".spa_trans.", an = "altblock." + std::to_string(b) + ".ang_trans.";
+    int rc = lfsr_ffn_b3_presplit(c->P.w(sp + "feed_forward.1.weight"), c->P.w(sp + "feed_forward.4.weight"), 128, 256, 128, c->P.packed + c->ffn_split_spa[b], lfsr_stream(stream));
+    if (!rc) rc = lfsr_ffn_b3_presplit(c->P.w(an + "feed_forward.1.weight"), c->P.w(an + "feed_forward.4.weight"), 64, 128, 64, c->P.packed + c->ffn_split_ang[b], lfsr_stream(stream));
+    if (rc) return rc;
+  }
   c->finalized = true;
   return LFSR_OK;
 }
@@ -119,6 +127,8 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
   RC(lfsr_lft_position_fwd(SPOS, APE, A, h, w, 64, stream));              // LFT.py:84-85
   const float* cur = BUF0;
   const bool no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;   // two-launch feed-forward (A/B runs)
+  const char* psel = getenv("LFSR_FFN_PRESPLIT");
+  const bool presplit = !(psel && psel[0] == '0');                    // LFSR_FFN_PRESPLIT=0: the kernel splits the weight chunks itself (A/B runs)
   const char* lf = getenv("LFSR_LN_FUSE");
   // LayerNorms formed inside the consuming kernel (see epit.cpp): feed_forward.0 inside the fused feed-forward by default; the attention norms inside the
   // q | k | v projection only with LFSR_LN_FUSE=2 (measured slower: 1464 against 143 + 795 us for SpaTrans at 32 patches); LFSR_LN_FUSE=0: all norms as launches
@@ -145,7 +155,7 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
     RC(lfsr_linear_fwd(C2, 64, 0, 64, P.w(an + "attention.out_proj.weight"), nullptr, cur, 64, 0, C1, 64, 0, npix, 64, 1.0f, stream));     // + token
     const float *afg = P.w(an + "feed_forward.0.weight"), *afb = P.w(an + "feed_forward.0.bias");
     rc = (ln_fuse && !no_ffn_fused) ? lfsr_ffn_ln_launch(C1, 64, 0, afg, afb, 1e-5f, P.w(an + "feed_forward.1.weight"), P.w(an + "feed_forward.4.weight"), C1, 64, 0,
-                                                         a_out, 64, 0, npix, 64, 128, 64, 0.0f, lfsr_stream(stream))
+                                                         a_out, 64, 0, npix, 64, 128, 64, 0.0f, lfsr_stream(stream), presplit ? P.packed + c->ffn_split_ang[b] : nullptr)
                                     : LFSR_E_ARG;
     if (rc == LFSR_E_ARG) {
       RC(lfsr_layernorm_fwd(C1, 64, 0, nullptr, 0, 0, 1, afg, afb, N64, 64, 0, npix, 64, 1e-5f, stream));
@@ -176,7 +186,7 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
     RC(lfsr_linear_fwd(TN, 128, 0, 128, P.w(sp + "attention.out_proj.weight"), nullptr, T, 128, 0, T2, 128, 0, npix, 128, 1.0f, stream));
     const float *sfg = P.w(sp + "feed_forward.0.weight"), *sfb = P.w(sp + "feed_forward.0.bias");
     rc = (ln_fuse && !no_ffn_fused) ? lfsr_ffn_ln_launch(T2, 128, 0, sfg, sfb, 1e-5f, P.w(sp + "feed_forward.1.weight"), P.w(sp + "feed_forward.4.weight"), T2, 128, 0,
-                                                         T, 128, 0, npix, 128, 256, 128, 0.0f, lfsr_stream(stream))
+                                                         T, 128, 0, npix, 128, 256, 128, 0.0f, lfsr_stream(stream), presplit ? P.packed + c->ffn_split_spa[b] : nullptr)
                                     : LFSR_E_ARG;
     if (rc == LFSR_E_ARG) {
       RC(lfsr_layernorm_fwd(T2, 128, 0, nullptr, 0, 0, 1, sfg, sfb, V, 128, 0, npix, 128, 1e-5f, stream));
