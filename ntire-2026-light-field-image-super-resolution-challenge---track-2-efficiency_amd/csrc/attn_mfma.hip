@@ -36,8 +36,9 @@ struct EpiAttnArgs {
   int L;           // n1 * n2
 };
 
-template <int NT>
+template <int NT, int N1>      // N1: the angular resolution when known at compile time (5: the BASELINE geometry; divisions by it become multiplies), 0: read from the arguments
 __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
+  const int n1 = N1 ? N1 : p.n1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LR = NT * 16;                 // padded sequence length
   constexpr int HEAD_FLOATS = LR * 16 * 2;    // K [LR][16] + V^T [16][LR]
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
       const int tok = idx >> 2, c = idx & 3;
       f32x4a kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
       if (tok < p.L) {
-        const int t2 = tok / p.n1, t1 = tok - t2 * p.n1;
+        const int t2 = tok / n1, t1 = tok - t2 * n1;
         const long long pix = base + t1 * p.st1 + t2 * p.st2;
         kv = *reinterpret_cast<const f32x4a*>(p.K + pix * p.k_stride + p.k_choff + head * 16 + 4 * c);
         vv = *reinterpret_cast<const f32x4a*>(p.V + pix * p.v_stride + p.v_choff + head * 16 + 4 * c);
@@ -86,13 +87,15 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
     const int qtok = qt * 16 + l15;
     const bool qok = qtok < p.L;
     const int qc = qok ? qtok : p.L - 1;
-    const int t2q = qc / p.n1, t1q = qc - t2q * p.n1;
+    const int t2q = qc / n1, t1q = qc - t2q * n1;
     const long long qpix = base + t1q * p.st1 + t2q * p.st2;
     f32x4a qb = *reinterpret_cast<const f32x4a*>(p.Q + qpix * p.q_stride + p.q_choff + head * 16 + 4 * g);
     qb *= p.scale;
-    const int lo = max(0, t2q - p.l2) * p.n1, hi = min(kmax, t2q + p.r2) * p.n1;
-    const int q2lo = (qt * 16) / p.n1, q2hi = min(p.L - 1, qt * 16 + 15) / p.n1;
-    const int klo = max(0, q2lo - p.l2) * p.n1, khi = min(kmax, q2hi + p.r2) * p.n1;
+    const int lo = max(0, t2q - p.l2) * n1, hi = min(kmax, t2q + p.r2) * n1;
+    const int kbase = 4 * g - lo;
+    const unsigned kwidth = (unsigned)(hi > lo ? hi - lo : 0);
+    const int q2lo = (qt * 16) / n1, q2hi = min(p.L - 1, qt * 16 + 15) / n1;
+    const int klo = max(0, q2lo - p.l2) * n1, khi = min(kmax, q2hi + p.r2) * n1;
     const int ktlo = klo >> 4, kthi = (khi - 1) >> 4;
 
     f32x4a S[NT];
@@ -110,8 +113,8 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qb.w, acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const float s = (key >= lo && key < hi) ? acc[r] : -INFINITY;
+          // key = kt 16 + 4 g + r is inside [lo, hi)  <=>  (unsigned)(key - lo) < hi - lo: one add, one compare
+          const float s = (unsigned)(kbase + (kt * 16 + r)) < kwidth ? acc[r] : -INFINITY;
           S[kt][r] = s;
           m = fmaxf(m, s);
         }
@@ -169,11 +172,13 @@ int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_attn_mfma<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_attn_mfma<NT, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_attn_mfma<NT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((k_epi_attn_mfma<NT>), dim3((unsigned)nblk), dim3(512), smem, st, p);
+  if (n1 == 5) hipLaunchKernelGGL((k_epi_attn_mfma<NT, 5>), dim3((unsigned)nblk), dim3(512), smem, st, p);
+  else hipLaunchKernelGGL((k_epi_attn_mfma<NT, 0>), dim3((unsigned)nblk), dim3(512), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
