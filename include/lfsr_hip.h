@@ -228,7 +228,10 @@ int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* p
                        const float* gamma, const float* beta, float* y, int y_stride, int y_choff, long long M, int C,
                        float eps, void* stream);
 /* nn.Linear (no transposes needed: weight (N,K) packed by lfsr_pack_conv_weight(O=N,C=K,taps=1)); K in {64,128,256};
- * y = act(x W^T + bias) + res;  slope 1 = identity, 0 = ReLU, else LeakyReLU. */
+ * y = act(x W^T + bias) + res;  slope 1 = identity, 0 = ReLU, else LeakyReLU.
+ * Arithmetic: fp32 in, fp32 out, fp32 accumulation.  The bias-free K = 64 / 128 case (and lfsr_ffn_*, lfsr_linear_ln_fwd, lfsr_up_tail_fwd's 1x1 conv) runs on the bf16
+ * MFMA pipe with every fp32 operand split EXACTLY into three bf16 terms (six products; error against fp64 no larger than the fp32-MFMA kernels': tools/b3_accuracy.py);
+ * the environment selectors LFSR_ROWGEMM=f32, LFSR_FFN=f32, LFSR_UPTAIL=v2 choose the fp32-MFMA kernels. */
 int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const float* w_packed, const float* bias,
                     const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
                     long long M, int N, float slope, void* stream);
