@@ -22,6 +22,9 @@ One JSON line on rank 0.
   roofline_classes  one line per other kernel class of the forward (and the stand-alone SAI<->MacPI / PixelShuffle kernels),
                     algorithmic bytes or flops / hipEvent time, against 8 TB/s (and the 6.3 TB/s a float4 copy reaches) or the
                     fp32 MFMA peak; taken in a separate untimed pass (events around every class cost ~0.8 ms per step).
+  other_workloads   (N = 1) configs[2] EPIT B = 8, configs[3] DistgSSR training step B = 8, configs[4] LFT 64-patch scene, run after the headline timing:
+                    value, ms_per_step, arithmetic, the dominant operator's in-run duration (event hooks of the library) and its executed-work
+                    roofline fraction; EPIT / LFT with their GEMMs on the three-term bf16 pipe and, beside it, with every GEMM on fp32 MFMA.
   cpu_baseline      SURVEY 8d: oracle/lfsr_torch_port.py (stock torch CPU ops = what the reference's CPU path runs), fp32,
                     B = 4 chunks, thread count = a short sweep around the physical cores this process may use; plus one line
                     each for configs 1, 3, 5 (rank 0, N = 1 only; bounded to ~30-40 s).
@@ -52,6 +55,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-check", action="store_true",
                     help="skip the B = 1 re-runs of the batch-independence check (profiling passes: keeps every launch of a kernel the same size)")
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="--gpus N self-launch: seconds after which a still-running rank is killed (with the others) and the run fails")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the configs[2] / [3] / [4] lines (EPIT, training step, LFT scene) of the default run")
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: 32 infer, 8 train / epit / lft)")
     ap.add_argument("--workload", choices=["infer", "train", "epit", "lft"], default="infer",
                     help="infer = configs[1] (headline, default); train = configs[3]: DistgSSR x4 fp32 train step, batch 8 per GPU, RCCL bucket "
@@ -64,20 +69,50 @@ def parse():
 # ------------------------------------------------------------------------------------------------------------------
 
 def launch_ranks(args):
+    """One FRESH child per rank (this process has not imported torch and never touches a GPU).  The parent polls: the first child that fails, or a
+    child still running after --rank-timeout seconds, takes the others down with it (terminate, then kill) and the parent exits non-zero, so one
+    hung rank cannot hold the caller's lease.  Rank 0's stdout goes through a temporary file (no pipe to fill up)."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0 or "")
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + args.rank_timeout
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = f"rank {bad[0]} exited with status {rcs[bad[0]]}"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            failed = f"rank(s) {[r for r, rc in enumerate(rcs) if rc is None]} still running after {args.rank_timeout} s"
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        sys.stderr.write(f"bench.py: {failed}; the other ranks were stopped\n")
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return 1 if failed else 0
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -282,9 +317,10 @@ def bench_model(args, rank, world, dev, dist):
     else:
         from lfsr_amd.dispatch import sr_scene
         scene = torch.from_numpy(synth_input((A * 128, A * 128), seed=3)).to(dev)      # 5x5x128x128 -> 64 patches -> (5,5,512,512)
-        el, y = timed_loop(lambda: sr_scene(lambda t, info=None: rt.forward(t), scene, A, S, minibatch=args.batch or 32), args, dev, dist)
+        el, y = timed_loop(lambda: sr_scene(lambda t, info=None: rt.forward(t), scene, A, S, minibatch=args.batch or 32, dst=0), args, dev, dist)
         per_step, wl = 64.0 / world, "configs[4]: LFT 5x5 x4 full-scene inference (5x5x128x128 -> 64 patches via LFdivide / LFintegrate)"
-        par = f"64 patches sharded over {world} rank(s), one all-gather of the SR patches"
+        par = (f"64 patches sharded over {world} rank(s); each rank crops its SR patches to the tiles LFintegrate keeps, one gather of the tiles "
+               "(26 MB per scene in total) to rank 0, which places them")
     if rank == 0:
         assert torch.isfinite(y).all()
         line = base_line(args, world, el, per_step, f"5x5 x4-SR LF patches/sec (32^2->128^2), {key} inference", wl, {"parallelism": par})
@@ -299,6 +335,133 @@ def bench_model(args, rank, world, dev, dist):
         line["config"]["gemm_arithmetic"] = {"rowgemm": "f32" if f32_sel[0] else "bf16x3", "ffn": "f32" if f32_sel[1] else "bf16x3", "up_tail": "f32" if f32_sel[2] else "bf16x3"}
         print(json.dumps(line), flush=True)
     finish(dist)
+
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (the three-term GEMMs issue six bf16 products per fp32 product)
+
+
+def _op_floor(op, a, b, npix, f32_gemms):
+    """executed work of one launch of an instrumented operator at `npix` token rows -> (bound, floor_us, what) against the gfx950 peaks, or None"""
+    if op in ("conv3x3", "conv3x3_dgrad"):       # Winograd F(4x4,3x3): 2.25 / 9 of the direct 2 x 576 x 64 flops per pixel, fp32 MFMA
+        m = a * b
+        fl, by = 2.0 * 576 * 64 * m * 2.25 / 9.0, 2.0 * m * 64 * 4
+        t = max(fl / (FP32_MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_TBPS * 1e12))
+        return "mfma-f32", t * 1e6, "k_conv3x3_wino4: 36 position-GEMMs per 8x32-pixel tile"
+    if op in ("linear", "linear_ln"):
+        fl, by = 2.0 * npix * a * b, npix * (a + b) * 4.0
+        tm = fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) if f32_gemms else 6.0 * fl / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        th = by / (HBM_PEAK_TBPS * 1e12)
+        return ("hbm" if th >= tm else ("mfma-f32" if f32_gemms else "mfma-bf16x3")), max(tm, th) * 1e6, f"row-GEMM K = {a}, N = {b}"
+    if op == "ffn":
+        fl, by = 4.0 * npix * a * b, 2.0 * npix * a * 4.0
+        tm = fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) if f32_gemms else 6.0 * fl / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+        th = by / (HBM_PEAK_TBPS * 1e12)
+        return ("hbm" if th >= tm else ("mfma-f32" if f32_gemms else "mfma-bf16x3")), max(tm, th) * 1e6, f"fused LayerNorm + {a} -> {b} -> {a} feed-forward"
+    if op == "window_attn":                      # q | k | v read + o written once, E = 8 heads x head dim; the windowed flops are far below the HBM floor
+        by = 4.0 * npix * 8 * a * 4.0
+        return "hbm", by / (HBM_PEAK_TBPS * 1e12) * 1e6, f"windowed attention, head dim {a}, {b} tokens per sequence"
+    return None
+
+
+def other_workloads(dev, budget_steps=(20, 10, 8)):
+    """configs[2], [3], [4] on this GPU after the headline (rank 0, N = 1): EPIT B = 8 and the LFT 64-patch scene with their GEMMs on the three-term bf16
+    pipe AND on fp32 MFMA, the DistgSSR training step at B = 8; each with its dominant operator's in-run duration (the library's event hooks,
+    capi.op_profile, in a separate untimed pass of 2 steps) and that operator's executed-work roofline fraction.  Template: check_efficiency_official.py:306-330."""
+    import importlib
+    from argparse import Namespace
+    import torch
+    from lfsr_amd import capi
+    from lfsr_amd.synth import synth_input, synth_state_dict
+    meta_all = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"]
+    F32_ENV = {"LFSR_ROWGEMM": "f32", "LFSR_FFN": "f32", "LFSR_UPTAIL": "v2"}
+    out = []
+
+    def timed(step, warm, steps):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def dominant(step, npix, f32_gemms, nprof=2):
+        step()
+        torch.cuda.synchronize()
+        capi.op_profile(True)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        tab = capi.op_profile_read()
+        capi.op_profile(False)
+        nested = {"epiconv_hv"}                  # (outer hooks that only wrap another hooked launch)
+        tab = {k: v for k, v in tab.items() if k[0] not in nested}
+        if not tab:
+            return None
+        tot = sum(ms for ms, _ in tab.values())
+        (op, a, b), (ms, n) = max(tab.items(), key=lambda kv: kv[1][0])
+        e = {"operator": op, "tags": [a, b], "avg_launch_us": ms / n * 1e3, "launches_per_step": n // nprof, "ms_per_step": ms / nprof,
+             "share_of_hooked_time": ms / tot, "hooked_ms_per_step": tot / nprof}
+        fl = _op_floor(op, a, b, npix, f32_gemms)
+        if fl:
+            e.update(bound=fl[0], floor_us=fl[1], frac=fl[1] / (ms / n * 1e3), kernel=fl[2])
+        e["by_operator_ms_per_step"] = {f"{k[0]}({k[1]},{k[2]})": v[0] / nprof for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:8]}
+        return e
+
+    def set_env(env):
+        for k in F32_ENV:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+
+    # ---- configs[2] EPIT B = 8 and configs[4] LFT scene: both arithmetic selections (read when the runtime is built and at every launch) ----
+    for name, key, steps in (("epit", "EPIT", budget_steps[0]), ("lft", "LFT", budget_steps[2])):
+        sd = synth_state_dict([(k, tuple(sh)) for k, sh in meta_all[key]["full"]["spec"]], seed=0)
+        lines = {}
+        for arith, env in (("bf16x3", {}), ("f32", F32_ENV)):
+            set_env(env)
+            rt = capi.ModelRuntime(name, A, S, 5 if name == "epit" else 4, 64)
+            rt.load_state([(k, torch.from_numpy(v).to(dev)) for k, v in sd.items()], dev)
+            if name == "epit":
+                x = torch.from_numpy(synth_input((8, 1, A * H, A * W), seed=1)).to(dev)
+                step, per_step, npix = (lambda: rt.forward(x)), 8, 8 * A * A * H * W
+            else:
+                from lfsr_amd.dispatch import sr_scene
+                scene = torch.from_numpy(synth_input((A * 128, A * 128), seed=3)).to(dev)
+                step, per_step, npix = (lambda: sr_scene(lambda t, info=None: rt.forward(t), scene, A, S, minibatch=32)), 64, 32 * A * A * H * W
+            sec = timed(step, 3, steps)
+            lines[arith] = {"value": per_step / sec, "ms_per_step": sec * 1e3, "dominant": dominant(step, npix, arith == "f32")}
+            del rt
+        set_env({})
+        b3, f32 = lines["bf16x3"], lines["f32"]
+        out.append({"config": "configs[2]: EPIT 5x5 x4 inference, batch 8 patches, 1 GPU" if name == "epit" else
+                              "configs[4]: LFT 5x5 x4 full-scene inference (5x5x128x128 -> 64 patches via LFdivide / LFintegrate, minibatch 32), 1 GPU",
+                    "value": b3["value"], "unit": "patches/s", "ms_per_step": b3["ms_per_step"], "steps": steps, "warmup": 3,
+                    "dtype": "f32 (linear / FFN / tail GEMMs: fp32 operands as three exact bf16 terms on the bf16 MFMA pipe, fp32 accumulation; 3x3 convs and attention: fp32 MFMA)",
+                    "gemm_arithmetic": "bf16x3", "dominant_kernel": b3["dominant"],
+                    "all_fp32_mfma": {"value": f32["value"], "ms_per_step": f32["ms_per_step"], "dtype": "f32", "gemm_arithmetic": "f32", "dominant_kernel": f32["dominant"]},
+                    "model_tflops_windowed": FLOP_PER_PATCH[name] * b3["value"] / 1e12})
+    # ---- configs[3] DistgSSR training step, B = 8 (fp32 MFMA only) ----
+    sys.path.insert(0, capi._HERE)
+    M = importlib.import_module("model.SR.DistgSSR")
+    sys.path.remove(capi._HERE)
+    from lfsr_amd.train_step import train_step
+    sd = synth_state_dict([(k, tuple(sh)) for k, sh in meta_all["DistgSSR"]["full"]["spec"]], seed=0)
+    net = M.get_model(Namespace(angRes_in=A, angRes_out=A, scale_factor=S))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(dev).train()
+    crit = M.get_loss(None)
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
+    x = torch.from_numpy(synth_input((8, 1, A * H, A * W), seed=1)).to(dev)
+    y = torch.from_numpy(synth_input((8, 1, A * H * S, A * W * S), seed=100)).to(dev)
+    step = lambda: train_step(net, crit, opt, x, y)
+    sec = timed(step, 3, budget_steps[1])
+    out.append({"config": "configs[3]: DistgSSR 5x5 x4 training step (fwd + bwd + clip + AdamW; the RCCL bucket all-reduce is a no-op at N = 1), batch 8, 1 GPU",
+                "value": 8 / sec, "unit": "patches/s", "ms_per_step": sec * 1e3, "steps": budget_steps[1], "warmup": 3, "dtype": "f32", "gemm_arithmetic": "f32",
+                "dominant_kernel": dominant(step, 8 * A * A * H * W, True), "model_tflops": 3 * FLOP_PER_PATCH["distgssr"] * 8 / sec / 1e12})
+    del net, opt
+    torch.cuda.empty_cache()
+    return out
 
 
 def index_micro(dev):
@@ -427,6 +590,10 @@ def bench_infer(args, rank, world, dev, dist):
         line["kernel_ms_per_step"] = {k: v[0] / nb for k, v in prof_all.items()}
         line["kernel_ms_per_step_note"] = f"separate untimed pass of {nb} steps with events around every operator class"
         line["batch_split_max_abs_diff"] = batch_split_max_abs_diff
+        if world == 1 and not args.no_other_workloads:
+            del rt
+            torch.cuda.empty_cache()
+            line["other_workloads"] = other_workloads(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, x_np)
         print(json.dumps(line), flush=True)
@@ -437,6 +604,20 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))     # before torch is imported or anything touches the GPU
+    hook = os.environ.get("LFSR_BENCH_TEST_RANK")     # launcher tests only (tests/test_bench_launcher.py): "ok" | "fail:<rank>" | "hang:<rank>", no torch, no GPU
+    if hook and "WORLD_SIZE" in os.environ:
+        me = int(os.environ["RANK"])
+        kind, _, who = hook.partition(":")
+        if kind == "ok":
+            if me == 0:
+                print(json.dumps({"ok": True, "world": int(os.environ["WORLD_SIZE"]), "port": os.environ["MASTER_PORT"]}), flush=True)
+            sys.exit(0)
+        if me == int(who):
+            if kind == "fail":
+                sys.exit(3)
+            time.sleep(600)
+        time.sleep(600 if kind == "fail" else 0)
+        sys.exit(0)
     rank, world, dev, dist = init_rank(args)
     if args.workload == "train":
         return bench_train(args, rank, world, dev, dist)

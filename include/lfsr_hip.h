@@ -67,6 +67,14 @@ int lfsr_lf_divide(const void* in, void* out, int A, int h0, int w0, int P, int 
 int lfsr_lf_integrate(const void* in, void* out, int A, int numU, int numV, int pz, int stride, int h, int w,
                       int elem_bytes, void* stream);
 
+/* LFintegrate factored for patch-sharded ranks (utils/utils.py:169-178 keeps only the centre stride x stride of every view of every SR patch):
+ * crop: in (count,A*pz,A*pz) SR patches -> tiles (count,A,A,stride,stride), run by the rank that computed the patches (a quarter of the bytes then
+ * crosses xGMI); place: the tiles of patches [first, first+count) of the row-major (numU,numV) list -> out (A,A,h,w), pixels beyond (h,w) dropped.
+ * place(crop(x)) over all patches == lfsr_lf_integrate(x), bit for bit. */
+int lfsr_lf_crop_tiles(const void* in, void* tiles, int A, int count, int pz, int stride, int elem_bytes, void* stream);
+int lfsr_lf_place_tiles(const void* tiles, void* out, int A, int numU, int numV, int first, int count, int stride, int h, int w,
+                        int elem_bytes, void* stream);
+
 /* NCHW <-> VCL (fp32).  layout: 0 = SAI mosaic, 1 = MacPI.  VCL side described by (stride, choff). */
 int lfsr_nchw_to_vcl(const float* in, float* out, int out_stride, int out_choff, int B, int C, int A, int h, int w,
                      int layout, void* stream);
@@ -171,6 +179,11 @@ int lfsr_distgssr_param_offset(const lfsr_distgssr* ctx, const char* key, size_t
 size_t lfsr_distgssr_train_workspace_bytes(const lfsr_distgssr* ctx, int B, int h, int w);
 int lfsr_distgssr_forward_train(lfsr_distgssr* ctx, const float* x, float* out, int B, int h, int w,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* parity aid: offset (in floats, into the training workspace) and size of an activation forward_train saved for the backward.  which: 0 SpaConv.0
+ * output (VCL, 64 ch), 1 the concat buffer (VCL, 144 ch), 2 AngConv.0 output (rows (b,y,x), 16 ch), 3 / 4 EPIConv.0 output of the horizontal /
+ * vertical pass (rows (b*A+u,y,x) / (b*A+v,y,x), 32 ch), 5 fuse.0 output (VCL, 64), 6 block output (VCL, 64); index = group * n_block + block.
+ * All are post-LeakyReLU values: their signs are the LeakyReLU' masks the data gradients apply (DistgSSR.py:79-101). */
+int lfsr_distgssr_train_saved(const lfsr_distgssr* ctx, int B, int h, int w, int which, int index, size_t* offset_floats, size_t* numel);
 /* dout (B,1,A*h*s,A*w*s) = dLoss/dOut; grads: n_grads == lfsr_distgssr_num_params(ctx) floats, overwritten */
 int lfsr_distgssr_backward(lfsr_distgssr* ctx, const float* x, const float* dout, int B, int h, int w,
                            void* workspace, size_t workspace_bytes, float* grads, size_t n_grads, void* stream);
@@ -330,6 +343,15 @@ int lfsr_internet_finalize(lfsr_internet* ctx, void* stream);
 size_t lfsr_internet_workspace_bytes(const lfsr_internet* ctx, int B, int h, int w);
 int lfsr_internet_forward(lfsr_internet* ctx, const float* x, float* out, int B, int h, int w, void* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* ---- operator-level timing hooks (measurement aid; the reference times whole forwards only: check_efficiency_official.py:306-330) ----
+ * lfsr_op_profile(1): from now on every instrumented operator entry point brackets its launches with a hipEvent pair on its launch stream (and any
+ * earlier records are dropped); lfsr_op_profile(0): off (the default; a hook then costs one atomic load).  lfsr_op_profile_read waits for the recorded
+ * events, writes one text line "op a b total_ms launches" per (operator, tag a, tag b) into buf (NUL-terminated, truncated to cap), clears the records and
+ * returns the bytes the full text needs, or a negative LFSR_E_* / HIP code.  Tags: conv3x3 / conv3x3_dgrad / conv3x3_wgrad (n_img, h*w), linear (K, N),
+ * window_attn (head dim, tokens per sequence), ffn (K, hidden), up_tail (scale, 0), epiconv / angconv / pointwise (cin, N). */
+int lfsr_op_profile(int enable);
+long long lfsr_op_profile_read(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,8 @@ SIGNATURES = {
     "lfsr_image_extend": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_lf_divide": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i), c_p]),
     "lfsr_lf_integrate": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_lf_crop_tiles": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "lfsr_lf_place_tiles": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_nchw_to_vcl": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_vcl_to_nchw": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "lfsr_pack_conv_weight": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -53,6 +55,7 @@ SIGNATURES = {
     "lfsr_distgssr_param_offset": (c_i, [c_p, C.c_char_p, C.POINTER(c_sz), C.POINTER(c_sz)]),
     "lfsr_distgssr_train_workspace_bytes": (c_sz, [c_p, c_i, c_i, c_i]),
     "lfsr_distgssr_forward_train": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p]),
+    "lfsr_distgssr_train_saved": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_sz), C.POINTER(c_sz)]),
     "lfsr_distgssr_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p, c_sz, c_p]),
     "lfsr_layernorm_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, C.c_longlong, C.c_longlong, c_p, c_p, c_p, c_i, c_i, C.c_longlong, c_i, c_f, c_p]),
     "lfsr_conv3x3_n_fwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
@@ -108,6 +111,8 @@ SIGNATURES = {
     "lfsr_comm_init": (c_i, [C.POINTER(c_p), c_i, c_i, c_p]),
     "lfsr_comm_destroy": (c_i, [c_p]),
     "lfsr_allreduce": (c_i, [c_p, c_sz, c_p, c_p]),
+    "lfsr_op_profile": (c_i, [c_i]),
+    "lfsr_op_profile_read": (C.c_longlong, [C.c_char_p, c_sz]),
     "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
     "lfsr_distgssr_profile_read": (c_i, [c_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
 }
@@ -163,6 +168,28 @@ def _elem(t):
     if eb not in (2, 4):
         raise LfsrError(f"unsupported element size {eb}")
     return eb
+
+
+def op_profile(enable):
+    """switch the library's operator-level timing hooks on (dropping earlier records) or off (lfsr_op_profile)"""
+    check(load().lfsr_op_profile(int(bool(enable))), "op_profile")
+
+
+def op_profile_read():
+    """-> {(op, a, b): (total_ms, launches)} of the hooks recorded since op_profile(True) / the last read; waits for the events"""
+    lib = load()
+    cap = 1 << 18
+    buf = C.create_string_buffer(cap)
+    need = lib.lfsr_op_profile_read(buf, cap)
+    if need < 0:
+        check(int(need), "op_profile_read")
+    if need > cap:
+        raise LfsrError(f"op_profile_read: table of {need} bytes truncated")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        op, a, b, ms, n = line.split()
+        out[(op, int(a), int(b))] = (float(ms), int(n))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -238,6 +265,29 @@ def lf_integrate(sub, A, pz, stride, h, w):
     n1, n2 = sub.shape[:2]
     out = torch.empty((A, A, h, w), dtype=sub.dtype, device=sub.device)
     check(lib.lfsr_lf_integrate(dev_ptr(sub), dev_ptr(out), A, n1, n2, pz, stride, h, w, _elem(sub), stream_ptr()), "lf_integrate")
+    return out
+
+
+def lf_crop_tiles(sub, A, pz, stride):
+    """(n,1,A*pz,A*pz) or (n,A*pz,A*pz) SR patches -> (n,A,A,stride,stride): what LFintegrate keeps of each patch (utils/utils.py:169-178)"""
+    lib = load()
+    n = sub.shape[0]
+    if sub.shape[-1] != A * pz or sub.shape[-2] != A * pz or sub.numel() != n * A * pz * A * pz:
+        raise LfsrError(f"lf_crop_tiles: bad patch tensor {tuple(sub.shape)} for A={A} pz={pz}")
+    sub = sub.contiguous()
+    out = torch.empty((n, A, A, stride, stride), dtype=sub.dtype, device=sub.device)
+    check(lib.lfsr_lf_crop_tiles(dev_ptr(sub), dev_ptr(out), A, n, pz, stride, _elem(sub), stream_ptr()), "lf_crop_tiles")
+    return out
+
+
+def lf_place_tiles(tiles, out, A, numU, numV, first, stride):
+    """tiles (count,A,A,stride,stride) of patches [first, first+count) -> their places in out (A,A,h,w), in place"""
+    lib = load()
+    tiles = tiles.contiguous()
+    if not out.is_contiguous() or out.dtype != tiles.dtype or out.shape[0] != A or out.shape[1] != A:
+        raise LfsrError("lf_place_tiles: bad output tensor")
+    check(lib.lfsr_lf_place_tiles(dev_ptr(tiles), dev_ptr(out), A, numU, numV, first, tiles.shape[0], stride, out.shape[2], out.shape[3], _elem(tiles), stream_ptr()),
+          "lf_place_tiles")
     return out
 
 
@@ -381,6 +431,15 @@ class DistgSSRRuntime:
         check(self.lib.lfsr_distgssr_backward(self.ctx, dev_ptr(x.contiguous()), dev_ptr(dout), B, h, w, dev_ptr(ws), ws.numel(),
                                               dev_ptr(grads), n, stream_ptr()), "distgssr_backward")
         return grads
+
+    def train_saved(self, x, which, index):
+        """the activation forward_train(x) saved for the backward, as a flat fp32 view of the training workspace (lfsr_distgssr_train_saved)"""
+        B, _, Hh, Ww = x.shape
+        h, w = Hh // self.A, Ww // self.A
+        off, n = c_sz(0), c_sz(0)
+        check(self.lib.lfsr_distgssr_train_saved(self.ctx, B, h, w, which, index, C.byref(off), C.byref(n)), "train_saved")
+        ws = self._train_workspace(B, h, w, x.device).view(torch.float32)
+        return ws[off.value:off.value + n.value]
 
     PROFILE_CLASSES = ("conv3x3", "angconv", "epiconv", "pointwise", "init_conv", "upsample_head")
 

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(512) void k_epi0_dgrad_lines(EpiDgradArgs p) {
 
 // LFSR_E_ARG = not covered (the caller keeps the gather-GEMM).  LFSR_DGRAD_EPI=gather forces the gather form (A/B runs).
 int lfsr_epi0_dgrad_launch(const float* dE, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, int vert, hipStream_t st) {
+  LfsrOpTimer op_t("epi0_dgrad", B, h * w, st);
   if (!dE || !w_direct || !dx || B <= 0 || h <= 0 || w <= 0 || ((dx_stride | dx_choff) & 3)) return LFSR_E_ARG;
   const char* sel = getenv("LFSR_DGRAD_EPI");
   if (A != 5 || (vert ? h : w) > 32 || (sel && sel[0] == 'g')) return LFSR_E_ARG;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void k_ang0_dgrad(const float* __restrict__ dA
 
 // LFSR_DGRAD_ANG=gather keeps the gather-GEMM (A/B runs); LFSR_E_ARG = not covered
 int lfsr_ang0_dgrad_launch(const float* dA16, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, hipStream_t st) {
+  LfsrOpTimer op_t("ang0_dgrad", B, h * w, st);
   if (!dA16 || !w_direct || !dx || B <= 0 || A <= 0 || h <= 0 || w <= 0 || ((dx_stride | dx_choff) & 3)) return LFSR_E_ARG;
   const char* sel = getenv("LFSR_DGRAD_ANG");
   if (sel && sel[0] == 'g') return LFSR_E_ARG;
@@ -344,6 +346,7 @@ int lfsr_add_inplace(float* a, const float* b, long long n, hipStream_t st) {
 }
 
 int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st) {
+  LfsrOpTimer op_t("bwd_gemm", g.in_mode * 16 + g.out_mode, g.N, st);
   GemmArgs p{};
   p.X = g.X; p.x_stride = g.x_stride; p.x_choff = g.x_choff; p.Wp = g.Wp; p.bias = nullptr;
   p.Y = g.Y; p.y_stride = g.y_stride; p.y_choff = g.y_choff;
@@ -372,12 +375,13 @@ int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st) {
 int lfsr_conv3x3_bwd_data(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, float* dx, int dx_stride, int dx_choff,
                           const float* r1, int r1_stride, int r1_choff, const float* mk, int mk_stride, int mk_choff, float mk_slope,
                           int n_img, int h, int w, hipStream_t st) {
+  LfsrOpTimer op_t("conv3x3_dgrad", n_img, h * w, st);
   const bool al = !((dy_stride | dy_choff | dx_stride | dx_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!mk || !((mk_stride | mk_choff) & 3));
   {
-    const char* sel = getenv("LFSR_CONV3X3");
+    const char* sel = lfsr_conv3_dgrad_sel();
     if (al && !(sel && (sel[0] == 'h' || sel[0] == 'g'))) {
       const int rc = lfsr_conv3x3_wino_launch(dy, dy_stride, dy_choff, wT_packed + LFSR_CONV3_DIRECT_FLOATS, wT_packed, dx, dx_stride, dx_choff, r1, r1_stride, r1_choff,
-                                              nullptr, 0, 0, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, 1.0f, st);
+                                              nullptr, 0, 0, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, 1.0f, sel, st);
       if (rc != LFSR_E_ARG) return rc;   // (E_ARG: a geometry the Winograd launchers do not cover -> the direct kernel)
     }
   }

@@ -464,8 +464,7 @@ __global__ __launch_bounds__(256) void k_pack_wino(const float* __restrict__ dir
 
 }  // namespace
 
-int lfsr_conv3_variant_mask() {
-  const char* sel = getenv("LFSR_CONV3X3");
+static int conv3_sel_mask(const char* sel) {
   if (!sel) return LFSR_W_WINO4;
   if (sel[0] == 'h' || sel[0] == 'g') return 0;                              // direct kernels: the direct pack only
   if (sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o') {
@@ -475,6 +474,12 @@ int lfsr_conv3_variant_mask() {
   }
   return LFSR_W_WINO4;
 }
+
+// LFSR_CONV3X3 selects the forward kernel; LFSR_DGRAD3 (same vocabulary) the data-gradient kernel, which otherwise follows LFSR_CONV3X3
+const char* lfsr_conv3_fwd_sel() { return getenv("LFSR_CONV3X3"); }
+const char* lfsr_conv3_dgrad_sel() { const char* d = getenv("LFSR_DGRAD3"); return d ? d : getenv("LFSR_CONV3X3"); }
+
+int lfsr_conv3_variant_mask() { return conv3_sel_mask(lfsr_conv3_fwd_sel()) | conv3_sel_mask(lfsr_conv3_dgrad_sel()); }
 
 int lfsr_pack_wino_m(const float* direct_packed, float* out, int mask, hipStream_t st) {
   if (!direct_packed || !out) return LFSR_E_ARG;
@@ -495,10 +500,9 @@ int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st) { ret
 int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const float* w_wino, const float* w_direct, float* y, int y_stride, int y_choff,
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
-                             int n_img, int h, int w, float slope, hipStream_t st) {
+                             int n_img, int h, int w, float slope, const char* sel, hipStream_t st) {
   {   // F(4x4,3x3): the symmetric-wave kernel (conv3x3_wino4s.hip, LFSR_CONV3X3=wino4s) or the specialised-wave one (conv3x3_wino4.hip);
       // LFSR_CONV3X3=wino2 keeps this file's F(2x2,3x3) kernel (A/B runs), as do operands the F(4x4) launchers do not cover
-    const char* sel = getenv("LFSR_CONV3X3");
     const bool is_w = sel && sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o';
     if (is_w && sel[4] == '4' && sel[5] == 'b') {
       const int rc = lfsr_conv3x3_wino4b_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS, y, y_stride, y_choff,
@@ -518,7 +522,7 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
   }
   // this file's F(2x2) kernel runs only when LFSR_CONV3X3 selects it (the runtimes pack only the selected copies): operands the F(4x4)
   // launchers do not cover (1 GiB and more) go to the callers' direct 9-tap kernel
-  if (!(lfsr_conv3_variant_mask() & LFSR_W_WINO2)) return LFSR_E_ARG;
+  if (!(conv3_sel_mask(sel) & LFSR_W_WINO2)) return LFSR_E_ARG;
   static std::atomic<bool> attr_set[64];
   static std::atomic<int> cus[64];
   int dev = 0;

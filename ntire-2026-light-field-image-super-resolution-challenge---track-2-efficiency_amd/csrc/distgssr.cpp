@@ -412,6 +412,30 @@ size_t lfsr_distgssr_train_workspace_bytes(const lfsr_distgssr* c, int B, int h,
   return t.total * sizeof(float);
 }
 
+// Diagnostic / parity aid: where forward_train left the activations the backward reads (post-LeakyReLU values, so their signs are the LeakyReLU'
+// masks of the data gradients).  which: 0 S1 (SpaConv.0 out, VCL 64), 1 CAT (VCL 144: Spa | Ang | EpiH | EpiV), 2 A16 (AngConv.0 out, rows (b,y,x), 16),
+// 3 EH / 4 EV (EPIConv.0 out, rows (b*A+u,y,x) / (b*A+v,y,x), 32), 5 FZ (fuse.0 out, VCL 64), 6 OUT (block output, VCL 64).  index = group * n_block + block.
+int lfsr_distgssr_train_saved(const lfsr_distgssr* c, int B, int h, int w, int which, int index, size_t* offset_floats, size_t* numel) {
+  if (!c || B <= 0 || h <= 0 || w <= 0 || index < 0 || index >= c->G * c->NB || !offset_floats || !numel) return LFSR_E_ARG;
+  TrainWs t;
+  float* const base = reinterpret_cast<float*>(uintptr_t(4096));   // any non-null base: only differences are used
+  train_layout(c, B, h, w, base, t);
+  const size_t npix = (size_t)B * c->A * c->A * h * w, nlr = (size_t)B * h * w, nepi = (size_t)B * c->A * h * w;
+  const float* p = nullptr; size_t n = 0;
+  switch (which) {
+    case 0: p = t.S1[index]; n = npix * 64; break;
+    case 1: p = t.CAT[index]; n = npix * 144; break;
+    case 2: p = t.A16[index]; n = nlr * 16; break;
+    case 3: p = t.EH[index]; n = nepi * 32; break;
+    case 4: p = t.EV[index]; n = nepi * 32; break;
+    case 5: p = t.FZ[index]; n = npix * 64; break;
+    case 6: p = t.OUT[index]; n = npix * 64; break;
+    default: return LFSR_E_ARG;
+  }
+  *offset_floats = (size_t)(p - base); *numel = n;
+  return LFSR_OK;
+}
+
 int lfsr_distgssr_forward_train(lfsr_distgssr* c, const float* x, float* out, int B, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
   if (!c || !x || !out || !workspace || B <= 0 || h <= 0 || w <= 0 || !c->finalized || ((uintptr_t)workspace & 15)) return LFSR_E_ARG;
   TrainWs t;

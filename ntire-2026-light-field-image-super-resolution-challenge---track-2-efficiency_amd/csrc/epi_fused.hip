@@ -521,6 +521,7 @@ bool lfsr_epi_fused_ok(int A, int h, int w) {
 
 int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* y, int y_stride,
                           int choffH, int choffV, float* t_h, float* t_v, int B, int A, int h, int w, int which, float slope, hipStream_t st) {
+  LfsrOpTimer op_t("epi_fused", B, h * w, st);
   // which: 1 = horizontal only, 2 = vertical only, 3 = both
   if (!lfsr_epi_fused_ok(A, h, w)) return LFSR_E_ARG;
   if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x

@@ -237,6 +237,7 @@ int launch_ffn(const FfnArgs& p, hipStream_t st) {
 int lfsr_ffn_ln_launch(const float* x, int x_stride, int x_choff, const float* ln_g, const float* ln_b, float ln_eps, const float* w1_packed, const float* w2_packed,
                        const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff,
                        long long M, int K1, int H, int N2, float slope, hipStream_t st, const void* wsplit) {
+  LfsrOpTimer op_t("ffn", K1, H, st);
   if (!x || !w1_packed || !w2_packed || !y || M <= 0 || H <= 0 || H % 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if ((ln_g != nullptr) != (ln_b != nullptr)) return LFSR_E_ARG;
   {   // default: the three-term bf16 form (ffn_b3.hip); LFSR_FFN=f32 keeps this file's fp32-MFMA kernel (A/B runs)

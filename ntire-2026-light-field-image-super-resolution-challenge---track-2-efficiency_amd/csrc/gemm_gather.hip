@@ -199,19 +199,20 @@ extern "C" {
 int lfsr_conv3x3_fwd(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
                      const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                      int n_img, int h, int w, float slope, void* stream) {
+  LfsrOpTimer op_t("conv3x3", n_img, h * w, lfsr_stream(stream));
   if (!x || !w_packed || !y || n_img <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < y_choff + 64 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if ((long long)n_img * h * w >= (1LL << 31) / 4) return LFSR_E_ARG;
   {
     // the tile kernels need 16-B aligned channel vectors on every operand; LFSR_CONV3X3 = halo | gather forces the direct
     // 9-tap halo kernel / the v1 gather-GEMM (A/B runs)
-    const char* sel = getenv("LFSR_CONV3X3");
+    const char* sel = lfsr_conv3_fwd_sel();
     const bool force_v1 = sel && sel[0] == 'g';
     const bool force_halo = sel && sel[0] == 'h';
     const bool al = !((y_stride | y_choff) & 3) && (!r1 || !((r1_stride | r1_choff) & 3)) && (!r2 || !((r2_stride | r2_choff) & 3));
     if (al && !force_v1 && !force_halo) {
       const int rc = lfsr_conv3x3_wino_launch(x, x_stride, x_choff, w_packed + LFSR_CONV3_DIRECT_FLOATS, w_packed, y, y_stride, y_choff, r1, r1_stride, r1_choff,
-                                              r2, r2_stride, r2_choff, nullptr, 0, 0, 1.0f, n_img, h, w, slope, lfsr_stream(stream));
+                                              r2, r2_stride, r2_choff, nullptr, 0, 0, 1.0f, n_img, h, w, slope, sel, lfsr_stream(stream));
       if (rc != LFSR_E_ARG) return rc;   // (E_ARG: a geometry the Winograd launchers do not cover -> the direct kernel)
     }
     if (al && !force_v1)
@@ -228,6 +229,7 @@ int lfsr_conv3x3_fwd(const float* x, int x_stride, int x_choff, const float* w_p
 
 int lfsr_pointwise_fwd(const float* x, int x_stride, int x_choff, int cin, const float* w_packed, const float* bias,
                        float* y, int y_stride, int y_choff, int M, int N, float slope, void* stream) {
+  LfsrOpTimer op_t("pointwise", cin, N, lfsr_stream(stream));
   if (!x || !w_packed || !y || M <= 0 || N <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + cin || y_stride < y_choff + N || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   GemmArgs p{};
@@ -251,6 +253,7 @@ int lfsr_pointwise_fwd(const float* x, int x_stride, int x_choff, int cin, const
 
 int lfsr_angconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
                      float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, float slope, void* stream) {
+  LfsrOpTimer op_t("angconv", B, h * w, lfsr_stream(stream));
   if (!x || !w1_packed || !w2_packed || !tmp || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < y_choff + 16 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   hipStream_t st = lfsr_stream(stream);
@@ -294,6 +297,7 @@ static bool epi_use_fused(int A, int h, int w) {
 
 int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
                      float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical, float slope, void* stream) {
+  LfsrOpTimer op_t("epiconv", B, h * w, lfsr_stream(stream));
   if (!x || !w1_packed || !w2_packed || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < y_choff + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if (epi_use_fused(A, h, w) && !((y_stride | y_choff) & 3) && (long long)B * A * A * h * w * x_stride * 4 < (1LL << 31))   // (16-B output vectors, 32-bit offsets)
@@ -304,6 +308,7 @@ int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
 
 int lfsr_epiconv_hv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
                         float* tmp, float* y, int y_stride, int choff_h, int choff_v, int B, int A, int h, int w, float slope, void* stream) {
+  LfsrOpTimer op_t("epiconv_hv", B, h * w, lfsr_stream(stream));
   if (!x || !w1_packed || !w2_packed || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < choff_h + 32 || y_stride < choff_v + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if (epi_use_fused(A, h, w) && !((y_stride | choff_h | choff_v) & 3) && (long long)B * A * A * h * w * x_stride * 4 < (1LL << 31))

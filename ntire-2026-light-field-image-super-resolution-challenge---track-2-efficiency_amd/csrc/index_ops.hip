@@ -277,6 +277,43 @@ inline unsigned grid_for(long long total) {
 
 }  // namespace
 
+// LFintegrate factored for patch-sharded ranks (utils/utils.py:169-178 keeps only the centre stride x stride of every view of every SR patch):
+// crop runs where a patch was computed, so a quarter of the SR bytes cross xGMI; place runs on the rank that assembles the scene.
+template <typename T>
+__global__ __launch_bounds__(256) void k_lf_crop_tiles(const T* __restrict__ in, T* __restrict__ tiles, int A, int count, int pz, int stride, int bdr) {
+  const long long total = (long long)count * A * A * stride * stride;
+  const int AP = A * pz;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int xx = (int)(idx % stride);
+    long long t = idx / stride;
+    int yy = (int)(t % stride);
+    t /= stride;
+    int a2 = (int)(t % A);
+    t /= A;
+    int a1 = (int)(t % A);
+    long long n = t / A;
+    tiles[idx] = in[(n * AP + a1 * pz + bdr + yy) * AP + a2 * pz + bdr + xx];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_lf_place_tiles(const T* __restrict__ tiles, T* __restrict__ out, int A, int numV, int first, int count, int stride, int h, int w) {
+  const long long total = (long long)count * A * A * stride * stride;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    int xx = (int)(idx % stride);
+    long long t = idx / stride;
+    int yy = (int)(t % stride);
+    t /= stride;
+    int a2 = (int)(t % A);
+    t /= A;
+    int a1 = (int)(t % A);
+    int n = first + (int)(t / A);
+    int n1 = n / numV, n2 = n - n1 * numV;
+    int Y = n1 * stride + yy, X = n2 * stride + xx;
+    if (Y < h && X < w) out[(((long long)a1 * A + a2) * h + Y) * w + X] = tiles[idx];
+  }
+}
+
 #define DISPATCH_ELEM(KERNEL, GRID, STREAM, ...)                                                        \
   do {                                                                                                  \
     if (elem_bytes == 4)                                                                                \
@@ -415,6 +452,28 @@ int lfsr_lf_integrate(const void* in, void* out, int A, int numU, int numV, int 
   int bdr = (pz - stride) / 2;
   long long total = (long long)A * A * h * w;
   DISPATCH_ELEM(k_lf_integrate, grid_for(total), lfsr_stream(stream), A, numU, numV, pz, stride, bdr, h, w);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_lf_crop_tiles(const void* in, void* out, int A, int count, int pz, int stride, int elem_bytes, void* stream) {
+  if (A <= 0 || count < 0 || pz <= 0 || stride <= 0 || pz < stride || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  long long total = (long long)count * A * A * stride * stride;
+  if (total == 0) return LFSR_OK;
+  if (!in || !out) return LFSR_E_ARG;
+  int bdr = (pz - stride) / 2;
+  DISPATCH_ELEM(k_lf_crop_tiles, grid_for(total), lfsr_stream(stream), A, count, pz, stride, bdr);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_lf_place_tiles(const void* in, void* out, int A, int numU, int numV, int first, int count, int stride, int h, int w, int elem_bytes, void* stream) {
+  if (A <= 0 || numU <= 0 || numV <= 0 || first < 0 || count < 0 || (long long)first + count > (long long)numU * numV || stride <= 0 || h <= 0 || w <= 0 ||
+      h > numU * stride || w > numV * stride || bad_elem(elem_bytes)) return LFSR_E_ARG;
+  long long total = (long long)count * A * A * stride * stride;
+  if (total == 0) return LFSR_OK;
+  if (!in || !out) return LFSR_E_ARG;
+  DISPATCH_ELEM(k_lf_place_tiles, grid_for(total), lfsr_stream(stream), A, numV, first, count, stride, h, w);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }

@@ -14,6 +14,18 @@ extern float* g_lfsr_diag_buf;
 extern "C" int lfsr_diag_set_buffer(float* buf);
 #endif
 
+// op_profile.cpp: operator-level timing hook (RAII).  Off (default): one relaxed atomic load.  On (lfsr_op_profile(1)): a hipEvent pair on `st` around
+// the scope, aggregated per (op, a, b) by lfsr_op_profile_read.  `op` must be a string literal.
+struct LfsrOpTimer {
+  LfsrOpTimer(const char* op, int a, int b, hipStream_t st);
+  ~LfsrOpTimer();
+  LfsrOpTimer(const LfsrOpTimer&) = delete;
+  LfsrOpTimer& operator=(const LfsrOpTimer&) = delete;
+ private:
+  int slot_;
+  hipStream_t st_;
+};
+
 // conv3x3_halo.hip
 int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
@@ -49,7 +61,9 @@ int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st);   //
 // training step and write only what the selected 3x3 kernel reads: lfsr_conv3_variant_mask() = the copies LFSR_CONV3X3 selects (default: wino4).
 // The selection is read when weights are packed AND when a conv is launched: set it before loading a model.
 enum { LFSR_W_WINO2 = 1, LFSR_W_WINO4 = 2, LFSR_W_WINO4S = 4, LFSR_W_WINO4B = 8, LFSR_W_ALL = 15 };
-int lfsr_conv3_variant_mask();
+int lfsr_conv3_variant_mask();          // union of the copies the forward (LFSR_CONV3X3) and the data-gradient (LFSR_DGRAD3) selections read
+const char* lfsr_conv3_fwd_sel();
+const char* lfsr_conv3_dgrad_sel();
 // Batched repack (training: every weight is repacked every step; one launch per pack KIND with a device-side descriptor table instead of one 4-us
 // launch per weight and layout).  kind 0: lfsr_pack_conv_weight's direct pack (perm 0 / 1), 1: lfsr_pack_weight_T (flip = taps reversed), 2: lfsr_pack_weight_chunkT.
 struct LfsrPackDesc { const float* src; float* dst; float* dst2; int kind, O, C, T, Npad, perm, ch, flip; };
@@ -69,7 +83,7 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
 int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const float* w_wino, const float* w_direct, float* y, int y_stride, int y_choff,
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
-                             int n_img, int h, int w, float slope, hipStream_t st);
+                             int n_img, int h, int w, float slope, const char* sel, hipStream_t st);
 // ang_fused.hip: the AngConv branch (conv AxA stride A 64->16, 1x1 16->16AA, PixelShuffle(A)) in one launch
 bool lfsr_ang_fused_ok(int A);
 int lfsr_ang_fused_launch(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed, float* t, float* y,

@@ -256,6 +256,7 @@ int lfsr_rowgemm_dgrad144_launch(const float* dy, int dy_stride, int dy_choff, c
 int lfsr_rowgemm_ln_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* ln_g, const float* ln_b, float ln_eps, int ln_cols,
                            const float* pe, int pe_stride, int pe_rows, int pe_div, float* y, int y_stride, int y_choff,
                            float* y2, int y2_stride, int y2_choff, int split_n, long long M, int N, hipStream_t st) {
+  LfsrOpTimer op_t("linear_ln", K, N, st);
   if (!x || !w_packed || !ln_g || !ln_b || !y || M <= 0 || N <= 0 || N % 64 || ln_cols % 64 || (y2 && (split_n % 64 || split_n <= 0 || split_n >= N))) return LFSR_E_ARG;
   if ((x_stride | x_choff | y_stride | y_choff) & 3 || (y2 && ((y2_stride | y2_choff) & 3)) || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
   if (x_stride < x_choff + K || y_stride < y_choff + (y2 ? split_n : N) || (y2 && y2_stride < y2_choff + N - split_n)) return LFSR_E_ARG;

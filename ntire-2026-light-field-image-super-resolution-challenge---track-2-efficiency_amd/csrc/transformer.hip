@@ -301,6 +301,7 @@ extern "C" {
 
 int lfsr_layernorm_fwd(const float* x, int x_stride, int x_choff, const float* pe, int pe_stride, long long pe_rows, long long pe_div, const float* gamma, const float* beta,
                        float* y, int y_stride, int y_choff, long long M, int C, float eps, void* stream) {
+  LfsrOpTimer op_t("layernorm", 0, 0, lfsr_stream(stream));
   if (!x || !gamma || !beta || !y || M <= 0 || (C != 64 && C != 128)) return LFSR_E_ARG;
   if ((x_stride | x_choff | y_stride | y_choff) & 3 || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
   const int rpb = 256 / (C / 4);
@@ -316,6 +317,7 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
                          float* o, int o_stride, int o_choff, int nheads, int hd,
                          int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
                          int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, void* stream) {
+  LfsrOpTimer op_t("window_attn", hd, n1 * n2, lfsr_stream(stream));
   if (!q || !k || !v || !o || nheads <= 0 || (hd != 8 && hd != 16) || ns0 <= 0 || ns1 <= 0 || ns2 <= 0 || n1 <= 0 || n2 <= 0) return LFSR_E_ARG;
   if ((q_stride | q_choff | k_stride | k_choff | v_stride | v_choff | o_stride | o_choff) & 3) return LFSR_E_ARG;
   AttnArgs p{};
@@ -383,6 +385,7 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
 
 int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const float* w_packed, const float* bias,
                     const float* res, int res_stride, int res_choff, float* y, int y_stride, int y_choff, long long M, int N, float slope, void* stream) {
+  LfsrOpTimer op_t("linear", cin, N, lfsr_stream(stream));
   if (!x || !w_packed || !y || M <= 0 || M >= (1LL << 31) || N <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + cin || y_stride < y_choff + N || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   GemmArgs p{};
@@ -405,6 +408,7 @@ int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const fl
 
 int lfsr_conv3x3_n_fwd(const float* x, int x_stride, int x_choff, const float* w_packed, float* y, int y_stride, int y_choff,
                        int n_img, int h, int w, int N, float slope, void* stream) {
+  LfsrOpTimer op_t("conv3x3_n", n_img, h * w, lfsr_stream(stream));
   // per-view 3x3 conv 64 -> N (any N): LFT's unfold(3x3)+Linear(576->128) token embedding (LFT.py:176-182)
   if (!x || !w_packed || !y || n_img <= 0 || h <= 0 || w <= 0 || N <= 0 || x_stride < x_choff + 64 || y_stride < y_choff + N || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   GemmArgs p{};

@@ -553,6 +553,7 @@ __global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
 
 extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const float* w0_packed, const float* w3, const float* x_lr, float* out,
                                 int B, int A, int h, int w, int s, float slope, void* stream) {
+  LfsrOpTimer op_t("up_tail", s, B, lfsr_stream(stream));
   if (!f || !w0_packed || !w3 || !x_lr || !out || B <= 0 || A <= 0 || h <= 0 || w <= 0 || (s != 2 && s != 4)) return LFSR_E_ARG;
   if (f_stride < f_choff + 64 || (f_stride | f_choff) & 3) return LFSR_E_ARG;
   const int smem = (2 * UT_ROWS * LDS_ROW + 2 * 64 * LDS_ROW + 64 * 9) * 4;

@@ -648,6 +648,7 @@ size_t lfsr_wgrad_partial_floats(int M, int ntaps, int N, int K) {
 
 int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff,
                       float* P, int M, int N, int K, int A, int h, int w, int ntaps, hipStream_t st) {
+  LfsrOpTimer op_t("wgrad_generic", gmode * 16 + xmode, N * 1000 + K, st);
   if (!G || !X || !P || M <= 0 || N <= 0 || N > 64 || (N & 3) || K <= 0 || (K & 3) || ntaps <= 0) return LFSR_E_ARG;
   if ((g_stride | g_choff | x_stride | x_choff) & 3) return LFSR_E_ARG;
   WgradArgs p{};
@@ -681,6 +682,7 @@ int lfsr_wgrad_conv3_blocks(int n_img, int h, int w) {
 
 int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P,
                             int n_img, int h, int w, hipStream_t st) {
+  LfsrOpTimer op_t("conv3x3_wgrad", n_img, h * w, st);
   if (!G || !X || !P || n_img <= 0 || h <= 0 || w <= 0 || ((g_stride | g_choff | x_stride | x_choff) & 3)) return LFSR_E_ARG;
   if ((long long)n_img * h * w * (x_stride > g_stride ? x_stride : g_stride) * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets
   static std::atomic<bool> attr_set[64];
@@ -715,6 +717,7 @@ int lfsr_wgrad_conv3_launch(const float* G, int g_stride, int g_choff, const flo
 
 int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, float* dW, int O, int C, int T, int perm, int ch,
                       int accumulate, int c_valid, int chunk_mode, hipStream_t st) {
+  LfsrOpTimer op_t("wgrad_reduce", O, C * T, st);
   if (c_valid <= 0 || c_valid > C) c_valid = C;
   if (!P || !dW || O <= 0 || C <= 0 || T <= 0) return LFSR_E_ARG;
   const int Npad = chunk_mode ? npad32(ch) : npad32(O);
@@ -751,6 +754,7 @@ int lfsr_wgrad_epi0_blocks(int B, int A, int h, int w, int vert) {
 }
 
 int lfsr_wgrad_epi0_launch(const float* dE, const float* dE_v, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st) {
+  LfsrOpTimer op_t("epi0_wgrad", B, h * w, st);
   if (!dE || !X || !P || B <= 0 || h <= 0 || w <= 0 || ((x_stride | x_choff) & 3) || vert < 0 || vert > 2 || (vert == 2 && !dE_v)) return LFSR_E_ARG;
   const char* sel = getenv("LFSR_WGRAD_EPI");
   if (A != 5 || (vert != 0 && h > 32) || (vert != 1 && w > 32) || (sel && sel[0] == 'g')) return LFSR_E_ARG;
@@ -781,6 +785,7 @@ int lfsr_wgrad_pw144_blocks(int M) {
 }
 
 int lfsr_wgrad_pw144_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P, int M, hipStream_t st) {
+  LfsrOpTimer op_t("pw144_wgrad", M, 0, st);
   if (!G || !X || !P || M <= 0 || ((g_stride | g_choff | x_stride | x_choff) & 3) || g_stride < g_choff + 64 || x_stride < x_choff + 144) return LFSR_E_ARG;
   const char* sel = getenv("LFSR_WGRAD_PW");
   if (sel && sel[0] == 'g') return LFSR_E_ARG;

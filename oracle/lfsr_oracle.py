@@ -97,6 +97,28 @@ def lf_integrate(sub, A, pz, stride, h, w):
     return np.ascontiguousarray(o[:, :, :h, :w])
 
 
+def lf_crop_tiles(sub, A, pz, stride):
+    """The per-patch half of ``LFintegrate`` (utils/utils.py:169-175): sub (n, A*pz, A*pz) [or (n,1,A*pz,A*pz)] -> (n, A, A, stride, stride),
+    the centre stride x stride of every view -- everything ``LFintegrate`` keeps of a patch."""
+    n = sub.shape[0]
+    v = sub.reshape(n, A, pz, A, pz)
+    bdr = (pz - stride) // 2
+    return np.ascontiguousarray(v[:, :, bdr:bdr + stride, :, bdr:bdr + stride].transpose(0, 1, 3, 2, 4))
+
+
+def lf_place_tiles(tiles, out, A, numU, numV, first, stride):
+    """The assembling half (utils/utils.py:176-178): tiles of patches [first, first+count) of the row-major (numU, numV) list go to
+    out[a1, a2, n1*stride + y, n2*stride + x], cropped at out's (h, w).  In place."""
+    h, w = out.shape[2:]
+    for k in range(tiles.shape[0]):
+        n1, n2 = divmod(first + k, numV)
+        y0, x0 = n1 * stride, n2 * stride
+        hh, ww = min(stride, h - y0), min(stride, w - x0)
+        if hh > 0 and ww > 0:
+            out[:, :, y0:y0 + hh, x0:x0 + ww] = tiles[k, :, :, :hh, :ww]
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # floating-point building blocks (stock PyTorch ops the reference calls)
 # ----------------------------------------------------------------------------------------------

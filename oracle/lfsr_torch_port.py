@@ -32,25 +32,35 @@ def pixel_shuffle1d(x, f):
     return x.reshape(B, f, C, H, W).permute(0, 2, 3, 4, 1).reshape(B, C, H, W * f)
 
 
-def distg_block(x, sd, pre, A):
-    """DisentgBlock.forward DistgSSR.py:104-111."""
-    lr = lambda t: F.leaky_relu(t, 0.1)
-    spa = lr(F.conv2d(x, sd[pre + "SpaConv.0.weight"], dilation=A, padding=A))
-    spa = lr(F.conv2d(spa, sd[pre + "SpaConv.2.weight"], dilation=A, padding=A))
-    ang = lr(F.conv2d(x, sd[pre + "AngConv.0.weight"], stride=A))
-    ang = F.pixel_shuffle(lr(F.conv2d(ang, sd[pre + "AngConv.2.weight"])), A)
+def distg_block(x, sd, pre, A, rec=None, force=None):
+    """DisentgBlock.forward DistgSSR.py:104-111.  rec: optional dict that receives the sign (> 0) of every LeakyReLU output of the block
+    (= the LeakyReLU' masks autograd applies), keyed pre + {S1, S2, A1, A2, EH1, EH2, EV1, EV2, FZ} in the reference's own layouts.
+    force: optional dict of such masks to APPLY instead of the sign test (y = t where mask else 0.1 t): the same graph with another
+    implementation's discrete LeakyReLU decisions -- what separates mask flips at pre-activations within round-off of zero from arithmetic error."""
+    def lr(t, tag=None):
+        if force is not None and tag:
+            y = torch.where(force[pre + tag], t, 0.1 * t)
+        else:
+            y = F.leaky_relu(t, 0.1)
+        if rec is not None and tag:
+            rec[pre + tag] = (y.detach() > 0)
+        return y
+    spa = lr(F.conv2d(x, sd[pre + "SpaConv.0.weight"], dilation=A, padding=A), "S1")
+    spa = lr(F.conv2d(spa, sd[pre + "SpaConv.2.weight"], dilation=A, padding=A), "S2")
+    ang = lr(F.conv2d(x, sd[pre + "AngConv.0.weight"], stride=A), "A1")
+    ang = F.pixel_shuffle(lr(F.conv2d(ang, sd[pre + "AngConv.2.weight"]), "A2"), A)
 
-    def epi(t):
-        e = lr(F.conv2d(t, sd[pre + "EPIConv.0.weight"], stride=(1, A), padding=(0, A * (A - 1) // 2)))
-        return pixel_shuffle1d(lr(F.conv2d(e, sd[pre + "EPIConv.2.weight"])), A)
-    epih = epi(x)
-    epiv = epi(x.permute(0, 1, 3, 2).contiguous()).permute(0, 1, 3, 2)
+    def epi(t, tag):
+        e = lr(F.conv2d(t, sd[pre + "EPIConv.0.weight"], stride=(1, A), padding=(0, A * (A - 1) // 2)), tag + "1")
+        return pixel_shuffle1d(lr(F.conv2d(e, sd[pre + "EPIConv.2.weight"]), tag + "2"), A)
+    epih = epi(x, "EH")
+    epiv = epi(x.permute(0, 1, 3, 2).contiguous(), "EV").permute(0, 1, 3, 2)
     buf = torch.cat((spa, ang, epih, epiv), dim=1)
-    buf = lr(F.conv2d(buf, sd[pre + "fuse.0.weight"]))
+    buf = lr(F.conv2d(buf, sd[pre + "fuse.0.weight"]), "FZ")
     return F.conv2d(buf, sd[pre + "fuse.2.weight"], dilation=A, padding=A) + x
 
 
-def distgssr_forward_graph(x, sd, A, s, n_group=4, n_block=4):
+def distgssr_forward_graph(x, sd, A, s, n_group=4, n_block=4, rec=None, force=None):
     """get_model.forward DistgSSR.py:29-36 with autograd left on (the gradient parity tests differentiate THIS with
     ``sd`` holding leaf tensors that require grad: the fp32 CPU forward + backward the reference's train.py:256-264 runs)."""
     x_up = F.interpolate(x, scale_factor=s, mode="bilinear", align_corners=False)
@@ -59,7 +69,7 @@ def distgssr_forward_graph(x, sd, A, s, n_group=4, n_block=4):
     for g in range(n_group):
         gin = buf
         for b in range(n_block):
-            buf = distg_block(buf, sd, f"disentg.Group.{g}.Block.{b}.", A)
+            buf = distg_block(buf, sd, f"disentg.Group.{g}.Block.{b}.", A, rec, force)
         buf = F.conv2d(buf, sd[f"disentg.Group.{g}.conv.weight"], dilation=A, padding=A) + gin
     buf = F.conv2d(buf, sd["disentg.conv.weight"], dilation=A, padding=A) + buf0
     up = F.conv2d(macpi2sai(buf, A), sd["upsample.0.weight"], sd["upsample.0.bias"])

@@ -23,6 +23,15 @@ class OracleOps:
     def integrate(sub, A, pz, stride, h, w):
         return torch.from_numpy(O.lf_integrate(sub.numpy(), A, pz, stride, h, w))
 
+    @staticmethod
+    def crop(sub, A, pz, stride):
+        return torch.from_numpy(O.lf_crop_tiles(sub.numpy(), A, pz, stride))
+
+    @staticmethod
+    def place(tiles, out, A, numU, numV, first, stride):
+        O.lf_place_tiles(tiles.numpy(), out.numpy(), A, numU, numV, first, stride)
+        return out
+
 
 def fake_net(x, info=None):
     # per-view nearest x4 of the SAI mosaic patch: (B,1,A*P,A*P) -> (B,1,A*P*4,A*P*4)
@@ -67,6 +76,9 @@ def _worker(rank, world, port, ret):
         lr2 = torch.arange(5 * 40 * 5 * 33, dtype=torch.float32).reshape(5 * 40, 5 * 33)
         out2 = sr_scene(fake_net, lr2, 5, 4, ops=OracleOps, minibatch=2)
         ok = ok and torch.equal(out2, expected(lr2, 5))
+        # dst = 1: only rank 1 assembles (one gather of the cropped tiles), the others get None
+        out3 = sr_scene(fake_net, lr2, 5, 4, ops=OracleOps, minibatch=3, dst=1)
+        ok = ok and ((out3 is None) if rank != 1 else torch.equal(out3, expected(lr2, 5)))
         # max-over-ranks clock reduction used by bench.py
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -74,6 +86,20 @@ def _worker(rank, world, port, ret):
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
+
+
+def test_integrate_is_place_of_crop():
+    """LFintegrate == place o crop on every patch subset split (the identity the sharded dispatcher rests on), incl. the ragged crop at (h, w)"""
+    rng = np.random.default_rng(3)
+    for A, numU, numV, pz, stride, h, w in ((5, 3, 3, 8, 4, 10, 9), (3, 2, 5, 16, 8, 16, 37), (2, 1, 1, 6, 2, 2, 1)):
+        sub = rng.standard_normal((numU, numV, A * pz, A * pz)).astype(np.float32)
+        want = O.lf_integrate(sub, A, pz, stride, h, w)
+        flat = sub.reshape(numU * numV, A * pz, A * pz)
+        for cut in (0, 1, numU * numV // 2, numU * numV):
+            out = np.full((A, A, h, w), np.nan, np.float32)
+            O.lf_place_tiles(O.lf_crop_tiles(flat[:cut], A, pz, stride), out, A, numU, numV, 0, stride)
+            O.lf_place_tiles(O.lf_crop_tiles(flat[cut:], A, pz, stride), out, A, numU, numV, cut, stride)
+            assert np.array_equal(out, want)
 
 
 def test_two_rank_scene_gloo():

@@ -60,3 +60,23 @@ def test_scene_baseline_sizes(model, h0, w0, npatch):
     assert n == npatch and tuple(out.shape) == (A, A, h0 * s, w0 * s)
     assert torch.isfinite(out).all()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("geom", [(5, 3, 3, 128, 64, 160, 132), (3, 2, 5, 64, 32, 64, 150), (2, 1, 1, 8, 4, 3, 4)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_crop_place_equal_integrate(geom, dtype):
+    """lfsr_lf_crop_tiles / lfsr_lf_place_tiles (what the sharded dispatcher exchanges) against the oracle and against lfsr_lf_integrate, bit for bit,
+    for any split of the patch list, incl. the ragged crop at (h, w) and an empty shard"""
+    A, numU, numV, pz, stride, h, w = geom
+    n = numU * numV
+    sub = torch.from_numpy(np.random.default_rng(5).standard_normal((n, A * pz, A * pz)).astype(np.float32)).to(dtype).cuda()
+    want = capi.lf_integrate(sub.reshape(numU, numV, A * pz, A * pz), A, pz, stride, h, w)
+    tiles = capi.lf_crop_tiles(sub, A, pz, stride)
+    assert np.array_equal(tiles.cpu().numpy(), O.lf_crop_tiles(sub.cpu().numpy(), A, pz, stride))
+    for cut in (0, 1, n // 2, n):
+        out = torch.full((A, A, h, w), float("nan"), dtype=dtype, device="cuda")
+        capi.lf_place_tiles(capi.lf_crop_tiles(sub[:cut], A, pz, stride), out, A, numU, numV, 0, stride)
+        capi.lf_place_tiles(capi.lf_crop_tiles(sub[cut:], A, pz, stride), out, A, numU, numV, cut, stride)
+        assert torch.equal(out, want)
+    with pytest.raises(capi.LfsrError):
+        capi.lf_place_tiles(tiles, torch.empty((A, A, h, w), dtype=dtype, device="cuda"), A, numU, numV, 1, stride)   # first + count beyond the list

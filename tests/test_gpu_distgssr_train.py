@@ -168,43 +168,68 @@ def _full_net():
 
 
 def test_grads_full_geometry_vs_torch_port_autograd():
-    """(A,h,w,s,B) = (5,32,32,4,2): every one of the 137 gradients.  Truth = fp64 autograd over the stock-torch CPU form of the oracle; the
-    yardstick = the SAME graph in fp32 (what the reference's train.py:256-264 computes on the CPU).  At this size fp32 itself does not hold
-    SURVEY 8d(iii)'s 1e-4 everywhere: LeakyReLU' flips at pre-activations within round-off of zero move the small angular / epipolar weight
-    tensors (measured: reference fp32 max 3.0e-4, p90 7e-5; HIP max 3.2e-4, p90 1.3e-4 -- the Winograd-form 3x3 convs of forward and data
-    gradient carry ~2x the round-off of the direct form).  Gates: per parameter rel-L2 <= max(1e-4, 3 x the reference-fp32 error) or <= 5e-4;
-    over all parameters median <= 5e-5, p90 <= 2e-4, max <= 5e-4, and at most a quarter of the tensors beyond 1e-4."""
+    """(A,h,w,s,B) = (5,32,32,4,2): every one of the 137 gradients at the BASELINE geometry (reference: train.py:256-264).
+    Truth = fp64 autograd over the stock-torch CPU form of the oracle; yardstick = the SAME graph in fp32 (what the reference computes on the CPU).
+
+    What round 3 measured (tools/grad_parity.py -> profiles/r03_grad_parity.json): at this size NEITHER implementation holds rel-L2 <= 1e-4 on every
+    tensor against fp64 (reference fp32: max 3-4e-4; HIP in every kernel selection, all-direct included: max 3-4e-4), and the cause is not arithmetic:
+    a few dozen of the 234 M LeakyReLU decisions sit within round-off of zero and come out on the other side (reference fp32: ~30 flips, HIP 33-71
+    depending on the conv form), and ONE flipped decision moves a small angular / epipolar weight tensor by 1-3e-4.  Which tensors are hit is chance,
+    so "per tensor <= 3 x the reference's error on that tensor" is ill-posed (the reference's own e_ref ranges over 2e-6 ... 4e-4 by where ITS flips
+    fell).  The error therefore is gated in its two parts, each against the reference's own figure for that part:
+      (i)  arithmetic: against the fp64 graph evaluated with the HIP forward's own LeakyReLU decisions (oracle `force=`), every tensor holds SURVEY's
+           rel-L2 <= 1e-4 (or 3 x the reference-fp32 figure of the same construction, which matters for upsample.0.bias only: a sum of +-1/N
+           that cancels to 1e-4 of its terms);
+      (ii) decisions: the HIP forward flips at most 4 x as many masks as the reference's fp32 forward does (and < 1e-6 of all decisions);
+      (iii) the total error's distribution stays within 4 x / 2 x / 2 x of the reference's median / p90 / max."""
     from oracle import lfsr_torch_port as T
+    from tests import helpers as TH
     A, h, w, s, B = 5, 32, 32, 4, 2
     M, net, sd = _full_net()
     x = synth_input((B, 1, A * h, A * w), seed=1)
     label = synth_input((B, 1, A * h * s, A * w * s), seed=2)
-    out = net(torch.from_numpy(x).cuda(), None)
+    xa = torch.from_numpy(x).cuda()
+    out = net(xa, None)
     loss = M.get_loss(None)(out, torch.from_numpy(label).cuda(), None)
+    blocks = [f"disentg.Group.{g}.Block.{b}." for g in range(4) for b in range(4)]
+    hip_masks = {pre + k: TH.hip_saved_mask(net._rt, xa, k, i) for i, pre in enumerate(blocks) for k in TH.MASK_KINDS}    # flat, HIP order; before backward
     loss.backward()
-    grads = {}
-    for dt in (torch.float32, torch.float64):
+    g_hip = {k: p.grad.detach().cpu().double() for k, p in net.named_parameters()}
+    assert all(torch.isfinite(g).all() for g in g_hip.values())
+
+    def cpu_graph(dt, force=None):
         sdt = {k: torch.from_numpy(v).to(dt).requires_grad_(True) for k, v in sd.items()}
+        rec = {} if force is None else None
         with torch.enable_grad():
-            rl = torch.nn.functional.l1_loss(T.distgssr_forward_graph(torch.from_numpy(x).to(dt), sdt, A, s), torch.from_numpy(label).to(dt))
+            rl = torch.nn.functional.l1_loss(T.distgssr_forward_graph(torch.from_numpy(x).to(dt), sdt, A, s, rec=rec, force=force), torch.from_numpy(label).to(dt))
         rl.backward()
         assert abs(loss.item() - rl.item()) < 1e-6
-        grads[dt] = {k: v.grad.double() for k, v in sdt.items()}
-    bad, rows = {}, []
-    for k, p in net.named_parameters():
-        g, r64, r32 = p.grad.detach().cpu().double(), grads[torch.float64][k], grads[torch.float32][k]
-        assert torch.isfinite(g).all(), k
-        n = r64.norm().clamp_min(1e-30)
-        e_hip, e_ref = float((g - r64).norm() / n), float((r32 - r64).norm() / n)
-        rows.append((e_hip, e_ref, k))
-        if e_hip > max(1e-4, 3.0 * e_ref) and e_hip > 5e-4:
-            bad[k] = (e_hip, e_ref)
-    eh = np.array(sorted(r[0] for r in rows)); er = np.array(sorted(r[1] for r in rows))
-    print("full geometry, rel-L2 vs fp64 autograd: HIP median %.2e p90 %.2e max %.2e | reference fp32 CPU median %.2e p90 %.2e max %.2e; worst HIP: %s" % (
-        np.median(eh), eh[int(0.9 * len(eh))], eh[-1], np.median(er), er[int(0.9 * len(er))], er[-1], max(rows)[2]))
-    print("tensors beyond 1e-4: HIP %d, reference fp32 %d of %d" % (int((eh > 1e-4).sum()), int((er > 1e-4).sum()), len(eh)))
-    assert not bad, bad
-    assert np.median(eh) <= 5e-5 and eh[int(0.9 * len(eh))] <= 2e-4 and eh[-1] <= 5e-4 and (eh > 1e-4).sum() <= len(eh) // 4
+        return {k: v.grad.double() for k, v in sdt.items()}, rec
+    g64, rec64 = cpu_graph(torch.float64)
+    g32, rec32 = cpu_graph(torch.float32)
+    nrm = {k: g.norm().clamp_min(1e-30) for k, g in g64.items()}
+    rel = lambda a, b: {k: float((a[k] - b[k]).norm() / nrm[k]) for k in nrm}
+    # (ii) decisions
+    n_dec = sum(m.numel() for m in hip_masks.values())
+    flips_hip = sum(int((hip_masks[k] != TH.ref_mask_to_hip(rec64[k], k.rsplit(".", 1)[1], B, A, h, w)).sum()) for k in hip_masks)
+    flips_ref = sum(int((rec32[k] != rec64[k]).sum()) for k in rec64)
+    # (i) arithmetic: the same graph with each implementation's own decisions
+    g64_hipmask, _ = cpu_graph(torch.float64, force={k: TH.hip_mask_to_ref(m, k.rsplit(".", 1)[1], B, A, h, w) for k, m in hip_masks.items()})
+    g64_refmask, _ = cpu_graph(torch.float64, force=rec32)
+    del rec64, rec32, hip_masks
+    ea_hip, ea_ref = rel(g_hip, g64_hipmask), rel(g32, g64_refmask)
+    e_hip, e_ref = rel(g_hip, g64), rel(g32, g64)
+    eh, er = np.array(sorted(e_hip.values())), np.array(sorted(e_ref.values()))
+    p90 = lambda v: v[int(0.9 * len(v))]
+    print("full geometry, rel-L2 vs fp64 autograd: HIP median %.2e p90 %.2e max %.2e | reference fp32 CPU median %.2e p90 %.2e max %.2e" % (
+        np.median(eh), p90(eh), eh[-1], np.median(er), p90(er), er[-1]))
+    print("LeakyReLU decisions flipped vs fp64: HIP %d, reference fp32 %d of %d" % (flips_hip, flips_ref, n_dec))
+    print("arithmetic-only error (own decisions forced into the fp64 graph): HIP max %.2e (%s) median %.2e | reference fp32 max %.2e median %.2e" % (
+        max(ea_hip.values()), max(ea_hip, key=ea_hip.get), np.median(list(ea_hip.values())), max(ea_ref.values()), np.median(list(ea_ref.values()))))
+    bad = {k: (ea_hip[k], ea_ref[k]) for k in ea_hip if ea_hip[k] > max(1e-4, 3.0 * ea_ref[k])}
+    assert not bad, bad                                                                   # (i)
+    assert flips_hip <= 4 * max(flips_ref, 16) and flips_hip < 1e-6 * n_dec               # (ii)
+    assert np.median(eh) <= 4 * np.median(er) and p90(eh) <= 2 * p90(er) and eh[-1] <= 2 * er[-1]   # (iii)
 
 
 def test_grad_bucket_b8_is_mean_of_b1_buckets():
