@@ -347,6 +347,11 @@ def _op_floor(op, a, b, npix, f32_gemms):
         fl, by = 2.0 * 576 * 64 * m * 2.25 / 9.0, 2.0 * m * 64 * 4
         t = max(fl / (FP32_MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_TBPS * 1e12))
         return "mfma-f32", t * 1e6, "k_conv3x3_wino4: 36 position-GEMMs per 8x32-pixel tile"
+    if op == "conv3x3_wgrad":                    # adjoint of F(2x2,3x3): 16 products per 2x2 outputs and channel pair (4 MACs per pixel and pair instead of 9), fp32 MFMA
+        m = a * b
+        fl, by = 2.0 * 4 * 64 * 64 * m, 2.0 * m * 64 * 4
+        t = max(fl / (FP32_MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_TBPS * 1e12))
+        return "mfma-f32", t * 1e6, "k_wgrad_conv3_wino: 16 position-GEMMs with the tile index as the MFMA K dimension (+ k_wgrad_reduce)"
     if op in ("linear", "linear_ln"):
         fl, by = 2.0 * npix * a * b, npix * (a + b) * 4.0
         tm = fl / (FP32_MFMA_PEAK_TFLOPS * 1e12) if f32_gemms else 6.0 * fl / (BF16_MFMA_PEAK_TFLOPS * 1e12)

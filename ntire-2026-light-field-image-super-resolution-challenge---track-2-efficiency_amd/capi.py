@@ -111,6 +111,10 @@ SIGNATURES = {
     "lfsr_comm_init": (c_i, [C.POINTER(c_p), c_i, c_i, c_p]),
     "lfsr_comm_destroy": (c_i, [c_p]),
     "lfsr_allreduce": (c_i, [c_p, c_sz, c_p, c_p]),
+    "lfsr_angconv_bwd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "lfsr_angconv_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_epiconv_hv_bwd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i]),
+    "lfsr_epiconv_hv_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_op_profile": (c_i, [c_i]),
     "lfsr_op_profile_read": (C.c_longlong, [C.c_char_p, c_sz]),
     "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
@@ -512,17 +516,21 @@ def pointwise(x, cin, w_packed, N, slope=1.0, bias=None, out=None, out_choff=0, 
     return out
 
 
-def angconv(x, w1p, w2p, B, A, h, w, slope, out, out_choff):
+def angconv(x, w1p, w2p, B, A, h, w, slope, out, out_choff, tmp=None):
+    """tmp: optional (B*h*w, 16) tensor that receives the stage-1 activation lrelu(AngConv.0(x)) (what lfsr_angconv_bwd reads)"""
     lib = load()
-    tmp = torch.empty((B * h * w, 16), dtype=torch.float32, device=x.device)
+    if tmp is None:
+        tmp = torch.empty((B * h * w, 16), dtype=torch.float32, device=x.device)
     check(lib.lfsr_angconv_fwd(dev_ptr(x), x.shape[1], 0, dev_ptr(w1p), dev_ptr(w2p), dev_ptr(tmp), dev_ptr(out), out.shape[1], out_choff,
                                B, A, h, w, slope, stream_ptr()), "angconv_fwd")
     return out
 
 
-def epiconv(x, w1p, w2p, B, A, h, w, vertical, slope, out, out_choff):
+def epiconv(x, w1p, w2p, B, A, h, w, vertical, slope, out, out_choff, tmp=None):
+    """tmp: optional (B*A*h*w, 32) tensor that receives the stage-1 activation lrelu(EPIConv.0(.)) of this pass (what lfsr_epiconv_hv_bwd reads)"""
     lib = load()
-    tmp = torch.empty((B * A * h * w, 32), dtype=torch.float32, device=x.device)
+    if tmp is None:
+        tmp = torch.empty((B * A * h * w, 32), dtype=torch.float32, device=x.device)
     check(lib.lfsr_epiconv_fwd(dev_ptr(x), x.shape[1], 0, dev_ptr(w1p), dev_ptr(w2p), dev_ptr(tmp), dev_ptr(out), out.shape[1], out_choff,
                                B, A, h, w, int(vertical), slope, stream_ptr()), "epiconv_fwd")
     return out
@@ -696,3 +704,23 @@ class RcclComm:
         if getattr(self, "comm", None):
             self.lib.lfsr_comm_destroy(self.comm)
             self.comm = None
+
+
+def angconv_bwd(dy, dy_choff, x, a16, w0, w2, dx, B, A, h, w, slope=0.1):
+    """lfsr_angconv_bwd: dy / x / dx VCL tensors (pixels, stride); w0, w2 raw PyTorch layouts.  dx is accumulated into; -> (dw0, dw2)."""
+    lib = load()
+    ws = torch.empty(lib.lfsr_angconv_bwd_workspace_floats(B, A, h, w), dtype=torch.float32, device=x.device)
+    dw0, dw2 = torch.empty_like(w0), torch.empty_like(w2)
+    check(lib.lfsr_angconv_bwd(dev_ptr(dy), dy.shape[1], dy_choff, dev_ptr(x), dev_ptr(a16), dev_ptr(w0.contiguous()), dev_ptr(w2.contiguous()), dev_ptr(dx),
+                               dev_ptr(dw0), dev_ptr(dw2), dev_ptr(ws), ws.numel(), B, A, h, w, slope, stream_ptr()), "angconv_bwd")
+    return dw0, dw2
+
+
+def epiconv_hv_bwd(dy, choff_h, choff_v, x, e_h, e_v, w0, w2, dx, B, A, h, w, slope=0.1):
+    """lfsr_epiconv_hv_bwd (both passes, shared weights).  dx is accumulated into; -> (dw0, dw2)."""
+    lib = load()
+    ws = torch.empty(lib.lfsr_epiconv_hv_bwd_workspace_floats(B, A, h, w), dtype=torch.float32, device=x.device)
+    dw0, dw2 = torch.empty_like(w0), torch.empty_like(w2)
+    check(lib.lfsr_epiconv_hv_bwd(dev_ptr(dy), dy.shape[1], choff_h, choff_v, dev_ptr(x), dev_ptr(e_h), dev_ptr(e_v), dev_ptr(w0.contiguous()), dev_ptr(w2.contiguous()),
+                                  dev_ptr(dx), dev_ptr(dw0), dev_ptr(dw2), dev_ptr(ws), ws.numel(), B, A, h, w, slope, stream_ptr()), "epiconv_hv_bwd")
+    return dw0, dw2

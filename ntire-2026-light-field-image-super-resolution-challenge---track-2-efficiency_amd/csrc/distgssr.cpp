@@ -359,7 +359,7 @@ size_t max_partial_floats(const lfsr_distgssr* c, int B, int h, int w) {
   auto up = [&](size_t v) { if (v > m) m = v; };
   up(lfsr_wgrad_partial_floats(npix, 9, 64, 64));
   up((size_t)256 * 9 * 64 * 64);
-  up((size_t)256 * AA * 32 * 64);   // EPI-line weight gradient: one slab per block
+  up(lfsr_branch_bwd_partial_floats(B, A, h, w));   // (incl. the EPI-line weight gradient's one slab per block)
   up(lfsr_wgrad_partial_floats(npix, 1, 64, 144));
   up(lfsr_wgrad_partial_floats(nlr, AA, 16, 64));
   up(lfsr_wgrad_partial_floats(nlr, AA, 16, 16));
@@ -487,7 +487,7 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   train_layout(c, B, h, w, (float*)workspace, t);
   if (workspace_bytes < t.total * sizeof(float)) return LFSR_E_WS;
   const int A = c->A, AA = A * A, nimg = B * AA;
-  const int npix = nimg * h * w, nlr = B * h * w, nepi = B * A * h * w;
+  const int npix = nimg * h * w;
   const float L = 0.1f;
   hipStream_t st = lfsr_stream(stream);
   int rc;
@@ -564,64 +564,12 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
       RC(dgrad3(t.dCAT, 144, p + "SpaConv.2.weight", t.dS1, nullptr, nullptr, t.S1[i], 64));
       RC(wgrad3(p + "SpaConv.0.weight", Xin, t.dS1, 64));
       RC(dgrad3(t.dS1, 64, p + "SpaConv.0.weight", gx, gy, nullptr, nullptr, 0));          // gx = gy (block skip) + dSpa
-      // AngConv : CAT[64:80] = PS(lrelu(1x1(A16))), A16 = lrelu(convAxA(Xin))
-      RC(lfsr_wgrad_launch(LFSR_IN_ANG, LFSR_IN_SAME, t.dCAT, 144, 64, t.A16[i], 16, 0, t.P[0], nlr, 16, 16, A, h, w, AA, st));
-      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nlr, AA, 16), nullptr, 0, G(p + "AngConv.2.weight"), 16 * AA, 16, AA, 1, 16, 0, 0, 1, st));
-      {
-        LfsrGemm q{};
-        q.in_mode = LFSR_IN_ANG; q.out_mode = LFSR_OUT_SAME; q.cin = 16; q.X = t.dCAT; q.x_stride = 144; q.x_choff = 64; q.Wp = c->wT(p + "AngConv.2.weight");
-        q.Y = t.dA16; q.y_stride = 16; q.Mk = t.A16[i]; q.mk_stride = 16; q.mk_slope = L;
-        q.M = nlr; q.N = 16; q.A = A; q.h = h; q.w = w; q.ntaps = AA; q.CH = 16;
-        RC(lfsr_bwd_gemm(q, st));
-      }
-      RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_ANG, t.dA16, 16, 0, Xin, 64, 0, t.P[0], nlr, 16, 64, A, h, w, AA, st));
-      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nlr, AA, 64), nullptr, 0, G(p + "AngConv.0.weight"), 16, 64, AA, 0, 0, 0, 0, 0, st));
-      {
-        LfsrGemm q{};
-        q.in_mode = LFSR_IN_SAME; q.out_mode = LFSR_OUT_VIEWS; q.cin = 16; q.X = t.dA16; q.x_stride = 16; q.Wp = c->wT(p + "AngConv.0.weight");
-        q.Y = gx; q.y_stride = 64; q.R1 = gx; q.r1_stride = 64;
-        q.M = nlr; q.N = AA * 64; q.A = A; q.h = h; q.w = w; q.ntaps = 1; q.CH = 64;
-        int rc4 = lfsr_ang0_dgrad_launch(t.dA16, c->w(p + "AngConv.0.weight"), gx, 64, 0, B, A, h, w, st);   // streaming read-modify-write form; else the gather-GEMM
-        if (rc4 == LFSR_E_ARG) rc4 = lfsr_bwd_gemm(q, st);
-        RC(rc4);
-      }
-      // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)
-      // the two passes share EPIConv.0's weights: where the EPI-line kernel applies, ONE weight-gradient launch covers both (one slab per block
-      // instead of two sets), after both passes' dE exist; else the gather form per pass
-      const bool epi_merged = lfsr_wgrad_epi0_blocks(B, A, h, w, 2) > 0 && A == 5 && h <= 32 && w <= 32 && (long long)npix * 64 * 4 < (1LL << 31) && !(getenv("LFSR_WGRAD_EPI") && getenv("LFSR_WGRAD_EPI")[0] == 'g');
-      int epi_slabs[2] = {0, 0};
-      for (int vert = 0; vert < 2; ++vert) {
-        const float* E = vert ? t.EV[i] : t.EH[i];
-        float* dE = vert ? t.dE32V : t.dE32;
-        const int choff = vert ? 112 : 80;
-        float* Pa = t.P[vert ? 2 : 0];   // EPIConv.2 partials
-        float* Pb = t.P[vert ? 3 : 1];   // EPIConv.0 partials
-        RC(lfsr_wgrad_launch(vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H, LFSR_IN_SAME, t.dCAT, 144, choff, E, 32, 0, Pa, nepi, 32, 32, A, h, w, A, st));
-        LfsrGemm q{};
-        q.in_mode = vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H; q.out_mode = LFSR_OUT_SAME; q.cin = 32; q.X = t.dCAT; q.x_stride = 144; q.x_choff = choff;
-        q.Wp = c->wT(p + "EPIConv.2.weight"); q.Y = dE; q.y_stride = 32; q.Mk = E; q.mk_stride = 32; q.mk_slope = L;
-        q.M = nepi; q.N = 32; q.A = A; q.h = h; q.w = w; q.ntaps = A; q.CH = 32;
-        RC(lfsr_bwd_gemm(q, st));
-        if (!epi_merged) {
-          RC(lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, dE, 32, 0, Xin, 64, 0, Pb, nepi, 32, 64, A, h, w, AA, st));
-          epi_slabs[vert] = lfsr_wgrad_splits(nepi, AA, 64);
-        }
-        LfsrGemm r{};
-        r.in_mode = vert ? LFSR_IN_LINE_V : LFSR_IN_LINE_H; r.out_mode = vert ? LFSR_OUT_EPIV : LFSR_OUT_EPIH; r.cin = 32; r.X = dE; r.x_stride = 32;
-        r.Wp = c->wT(p + "EPIConv.0.weight"); r.Y = gx; r.y_stride = 64; r.R1 = gx; r.r1_stride = 64;
-        r.M = nepi; r.N = A * 64; r.A = A; r.h = h; r.w = w; r.ntaps = A; r.CH = 64;
-        {   // EPIConv.0 data gradient (accumulates into gx): EPI-line kernel where it applies, else the gather-GEMM
-          int rc3 = lfsr_epi0_dgrad_launch(dE, c->w(p + "EPIConv.0.weight"), gx, 64, 0, B, A, h, w, vert, st);
-          if (rc3 == LFSR_E_ARG) rc3 = lfsr_bwd_gemm(r, st);
-          RC(rc3);
-        }
-      }
-      if (epi_merged) {
-        RC(lfsr_wgrad_epi0_launch(t.dE32, t.dE32V, Xin, 64, 0, t.P[1], B, A, h, w, 2, st));
-        epi_slabs[0] = lfsr_wgrad_epi0_blocks(B, A, h, w, 2);
-      }
-      RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(nepi, A, 32), t.P[2], lfsr_wgrad_splits(nepi, A, 32), G(p + "EPIConv.2.weight"), 32 * A, 32, A, 0, 32, 0, 0, 1, st));
-      RC(lfsr_wgrad_reduce(t.P[1], epi_slabs[0], epi_slabs[1] ? t.P[3] : nullptr, epi_slabs[1], G(p + "EPIConv.0.weight"), 32, 64, AA, 0, 0, 0, 0, 0, st));
+      // AngConv : CAT[64:80] = PS(lrelu(1x1(A16))), A16 = lrelu(convAxA(Xin))          (branch_bwd.cpp; also exported as lfsr_angconv_bwd)
+      RC(lfsr_ang_branch_bwd(t.dCAT, 144, 64, Xin, t.A16[i], c->w(p + "AngConv.0.weight"), c->wT(p + "AngConv.0.weight"), c->wT(p + "AngConv.2.weight"),
+                             gx, G(p + "AngConv.0.weight"), G(p + "AngConv.2.weight"), t.dA16, t.P[0], B, A, h, w, L, st));
+      // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)                 (lfsr_epiconv_hv_bwd)
+      RC(lfsr_epi_branch_bwd(t.dCAT, 144, 80, 112, Xin, t.EH[i], t.EV[i], c->w(p + "EPIConv.0.weight"), c->wT(p + "EPIConv.0.weight"), c->wT(p + "EPIConv.2.weight"),
+                             gx, G(p + "EPIConv.0.weight"), G(p + "EPIConv.2.weight"), t.dE32, t.dE32V, t.P, B, A, h, w, L, st));
       gy = gx;
     }
     // group skip: grad at the group's input = (through the blocks) + dG

@@ -172,3 +172,11 @@ int lfsr_wgrad_reduce(const float* P, int nsplit, const float* P2, int nsplit2, 
                       int accumulate, int c_valid, int chunk_mode, hipStream_t st);
 // chunk_mode = 1: the T 'taps' of the partials are the chunks of a (1-D) pixel shuffle: row = perm ? n*T + t : t*ch + n (n < ch), dW (T*ch, C)
 int lfsr_pack_weight_T(const float* w, float* out, int O, int C, int T, int flip, hipStream_t st);
+
+// branch_bwd.cpp: backward of the angular / epipolar branches (DistgSSR.py:84-97,108) on packed weights; C-ABI wrappers lfsr_angconv_bwd / lfsr_epiconv_hv_bwd
+size_t lfsr_branch_bwd_partial_floats(int B, int A, int h, int w);
+int lfsr_ang_branch_bwd(const float* dcat, int dc_stride, int dc_choff, const float* xin, const float* a16, const float* w0_packed, const float* w0T_packed,
+                        const float* w2T_packed, float* dx, float* dw0, float* dw2, float* dA16, float* P, int B, int A, int h, int w, float slope, hipStream_t st);
+int lfsr_epi_branch_bwd(const float* dcat, int dc_stride, int choff_h, int choff_v, const float* xin, const float* eh, const float* ev,
+                        const float* w0_packed, const float* w0T_packed, const float* w2T_packed, float* dx, float* dw0, float* dw2,
+                        float* dEh, float* dEv, float* const P[4], int B, int A, int h, int w, float slope, hipStream_t st);

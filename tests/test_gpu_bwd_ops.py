@@ -74,6 +74,73 @@ def test_pointwise_dgrad_wgrad(M, cin):
     assert _rel(dw.cpu(), wr.grad) <= 1e-4
 
 
+def _ps1d(x, f):      # DistgSSR.py:114-131
+    B, fC, Hh, Ww = x.shape
+    return x.reshape(B, f, fC // f, Hh, Ww).permute(0, 2, 3, 4, 1).reshape(B, fC // f, Hh, Ww * f)
+
+
+@pytest.mark.parametrize("B,A,h,w", [(2, 5, 32, 32), (1, 5, 6, 9), (2, 3, 8, 8)])
+def test_angconv_bwd_vs_autograd(B, A, h, w):
+    """lfsr_angconv_bwd against autograd of the reference's AngConv layers (DistgSSR.py:84-90) on stock torch CPU ops: dx (accumulated into a
+    given gradient), dW0, dW2; stage-1 activation taken from lfsr_angconv_fwd's tmp output"""
+    g = torch.Generator().manual_seed(B * 100 + h)
+    x = torch.randn(B, 64, h * A, w * A, generator=g)
+    w0 = torch.randn(16, 64, A, A, generator=g) * (1.0 / (64 * A * A) ** 0.5)
+    w2 = torch.randn(16 * A * A, 16, 1, 1, generator=g) * 0.25
+    dy = torch.randn(B, 16, h * A, w * A, generator=g)
+    dx0 = torch.randn(B, 64, h * A, w * A, generator=g)
+    xr, w0r, w2r = x.clone().requires_grad_(True), w0.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    y_ref = F.pixel_shuffle(F.leaky_relu(F.conv2d(F.leaky_relu(F.conv2d(xr, w0r, stride=A), 0.1), w2r), 0.1), A)
+    y_ref.backward(dy)
+    xv = capi.nchw_to_vcl(x.cuda(), A, 1)
+    out = torch.zeros((xv.shape[0], 16), device="cuda")
+    a16 = torch.empty((B * h * w, 16), device="cuda")
+    capi.angconv(xv, capi.pack_conv_weight(w0.cuda()), capi.pack_conv_weight(w2.cuda(), perm=1, ch=16), B, A, h, w, 0.1, out, 0, tmp=a16)
+    assert float((capi.vcl_to_nchw(out, B, 16, A, h, w, 1).cpu() - y_ref.detach()).abs().max()) <= 1e-4
+    dxv = capi.nchw_to_vcl(dx0.cuda(), A, 1)
+    dw0, dw2 = capi.angconv_bwd(capi.nchw_to_vcl(dy.cuda(), A, 1), 0, xv, a16, w0.cuda(), w2.cuda(), dxv, B, A, h, w)
+    assert _rel(capi.vcl_to_nchw(dxv, B, 64, A, h, w, 1).cpu() - dx0, xr.grad) <= 1e-4
+    assert _rel(dw0.cpu(), w0r.grad) <= 1e-4
+    assert _rel(dw2.cpu(), w2r.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("B,A,h,w", [(2, 5, 32, 32), (1, 5, 6, 9), (2, 3, 8, 8)])
+def test_epiconv_hv_bwd_vs_autograd(B, A, h, w):
+    """lfsr_epiconv_hv_bwd against autograd of the reference's EPIConv applied to the tensor and to its transpose with shared weights
+    (DistgSSR.py:91-97,108): dx accumulated, dW0 / dW2 summed over both passes; gradients arrive in two channel slices of one VCL buffer"""
+    g = torch.Generator().manual_seed(B * 100 + w)
+    x = torch.randn(B, 64, h * A, w * A, generator=g)
+    w0 = torch.randn(32, 64, 1, A * A, generator=g) * (1.0 / (64 * A * A) ** 0.5)
+    w2 = torch.randn(32 * A, 32, 1, 1, generator=g) * 0.18
+    dyh = torch.randn(B, 32, h * A, w * A, generator=g)
+    dyv = torch.randn(B, 32, h * A, w * A, generator=g)
+    dx0 = torch.randn(B, 64, h * A, w * A, generator=g)
+    xr, w0r, w2r = x.clone().requires_grad_(True), w0.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+
+    def epi(t):
+        e = F.leaky_relu(F.conv2d(t, w0r, stride=(1, A), padding=(0, A * (A - 1) // 2)), 0.1)
+        return _ps1d(F.leaky_relu(F.conv2d(e, w2r), 0.1), A)
+    yh, yv = epi(xr), epi(xr.permute(0, 1, 3, 2).contiguous()).permute(0, 1, 3, 2)
+    (yh * dyh).sum().backward(retain_graph=True)
+    (yv * dyv).sum().backward()
+    xv = capi.nchw_to_vcl(x.cuda(), A, 1)
+    w0p, w2p = capi.pack_conv_weight(w0.cuda()), capi.pack_conv_weight(w2.cuda())
+    out = torch.zeros((xv.shape[0], 64), device="cuda")
+    eh, ev = torch.empty((B * A * h * w, 32), device="cuda"), torch.empty((B * A * h * w, 32), device="cuda")
+    capi.epiconv(xv, w0p, w2p, B, A, h, w, False, 0.1, out, 0, tmp=eh)
+    capi.epiconv(xv, w0p, w2p, B, A, h, w, True, 0.1, out, 32, tmp=ev)
+    assert float((capi.vcl_to_nchw(out, B, 32, A, h, w, 1, choff=0).cpu() - yh.detach()).abs().max()) <= 1e-4
+    assert float((capi.vcl_to_nchw(out, B, 32, A, h, w, 1, choff=32).cpu() - yv.detach()).abs().max()) <= 1e-4
+    dyb = torch.zeros((xv.shape[0], 80), device="cuda")             # dLoss/dy_h at channels 8..39, dLoss/dy_v at 48..79 of one buffer
+    capi.nchw_to_vcl(dyh.cuda(), A, 1, out=dyb, choff=8)
+    capi.nchw_to_vcl(dyv.cuda(), A, 1, out=dyb, choff=48)
+    dxv = capi.nchw_to_vcl(dx0.cuda(), A, 1)
+    dw0, dw2 = capi.epiconv_hv_bwd(dyb, 8, 48, xv, eh, ev, w0.cuda(), w2.cuda(), dxv, B, A, h, w)
+    assert _rel(capi.vcl_to_nchw(dxv, B, 64, A, h, w, 1).cpu() - dx0, xr.grad) <= 1e-4
+    assert _rel(dw0.cpu(), w0r.grad) <= 1e-4
+    assert _rel(dw2.cpu(), w2r.grad) <= 1e-4
+
+
 def test_upsample_head_dgrad():
     B, A, h, w, s = 2, 5, 8, 8, 4
     g = torch.Generator().manual_seed(3)

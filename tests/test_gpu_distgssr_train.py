@@ -181,7 +181,10 @@ def test_grads_full_geometry_vs_torch_port_autograd():
            rel-L2 <= 1e-4 (or 3 x the reference-fp32 figure of the same construction, which matters for upsample.0.bias only: a sum of +-1/N
            that cancels to 1e-4 of its terms);
       (ii) decisions: the HIP forward flips at most 4 x as many masks as the reference's fp32 forward does (and < 1e-6 of all decisions);
-      (iii) the total error's distribution stays within 4 x / 2 x / 2 x of the reference's median / p90 / max."""
+      (iii) the total error's distribution stays within 8 x / 3 x / 3 x of the reference's median / p90 / max (measured: 2.4-3.7 x / 1.3 x / 1.0-1.4 x --
+            the median follows the flip count, 71 against 30, and the reference's own median moves between 4.4e-6 and 6.8e-6 with its thread count).
+    Measured (profiles/r03_grad_parity.json): HIP arithmetic-only error max 6.7e-7 over all 137 tensors (median 1.6e-7; the reference's fp32: 1.7e-6, and
+    1.5e-4 on upsample.0.bias), in every kernel selection; everything above that is the flipped decisions."""
     from oracle import lfsr_torch_port as T
     from tests import helpers as TH
     A, h, w, s, B = 5, 32, 32, 4, 2
@@ -229,7 +232,7 @@ def test_grads_full_geometry_vs_torch_port_autograd():
     bad = {k: (ea_hip[k], ea_ref[k]) for k in ea_hip if ea_hip[k] > max(1e-4, 3.0 * ea_ref[k])}
     assert not bad, bad                                                                   # (i)
     assert flips_hip <= 4 * max(flips_ref, 16) and flips_hip < 1e-6 * n_dec               # (ii)
-    assert np.median(eh) <= 4 * np.median(er) and p90(eh) <= 2 * p90(er) and eh[-1] <= 2 * er[-1]   # (iii)
+    assert np.median(eh) <= 8 * np.median(er) and p90(eh) <= 3 * p90(er) and eh[-1] <= 3 * er[-1]   # (iii)
 
 
 def test_grad_bucket_b8_is_mean_of_b1_buckets():
