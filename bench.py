@@ -518,6 +518,22 @@ def bench_infer(args, rank, world, dev, dist):
     rt.profile(3)
     el, y = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
     prof = rt.profile_read()
+    # the same timed loop with every GEMM of the forward on fp32 MFMA (LFSR_EPI=wino: the F(2,5) fp32 kernel of the EPI branch; LFSR_ROWGEMM=f32: fuse.0 on the
+    # fp32 row-GEMM): printed beside the headline whenever the headline uses the exact three-term bf16 form for those two operators
+    user_sel = {k: os.environ.get(k) for k in ("LFSR_EPI", "LFSR_ROWGEMM")}
+    b3_ops = [k for k, v in user_sel.items() if not (v and v[:1] in ("w", "d", "f", "g", "1"))]
+    el_f32 = None
+    if b3_ops:
+        os.environ.update(LFSR_EPI="wino", LFSR_ROWGEMM="f32")
+        for _ in range(2):
+            rt.forward(x)
+        el_f32, _ = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
+        for k, v in user_sel.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        rt.forward(x)
     rt.profile(1)
     nb = 3
     for _ in range(nb):
@@ -556,6 +572,13 @@ def bench_infer(args, rank, world, dev, dist):
                          f"configs[1]: DistgSSR 5x5 x4 inference, batch {B} patches per GPU (5x5 views of 32x32 -> 128x128)",
                          {"parallelism": f"patch-sharded x{world}, no data-path collective",
                           "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"})
+        if b3_ops:
+            line["dtype"] = ("f32 (EPI branch stage 1 / 2 and fuse.0: fp32 operands as three exact bf16 terms on the bf16 MFMA pipe, six products, fp32 accumulation -- "
+                             "error against fp64 not above the fp32-MFMA kernels', tests/test_gpu_b3_accuracy.py; 3x3 convs, angular branch, init, head: fp32 MFMA)")
+            line["config"]["gemm_arithmetic"] = {"conv3x3": "f32", "epiconv": "bf16x3" if "LFSR_EPI" in b3_ops else "f32", "fuse.0": "bf16x3" if "LFSR_ROWGEMM" in b3_ops else "f32",
+                                                 "angconv": "f32", "head": "f32"}
+            line["all_fp32_mfma"] = {"value": world * B * args.steps / el_f32, "unit": "patches/s", "ms_per_step": el_f32 / args.steps * 1e3, "dtype": "f32",
+                                     "selection": "LFSR_EPI=wino LFSR_ROWGEMM=f32 (same process, same weights, timed right after the headline loop)"}
         line["roofline"] = {
             "bound": "mfma", "achieved": exec_flop / conv_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": max(mfma_floor, hbm_floor) / conv_s, "traffic": traffic, "traffic_source": tsrc,
@@ -567,11 +590,16 @@ def bench_infer(args, rank, world, dev, dist):
                     "2 x 576 x 64 x pixels / time may exceed the peak and is not a roofline figure"}
         # per-class lines: algorithmic bytes (one read of every input + one write of every output, fp32) and flops per launch at this B
         npx = float(M)
+        epi_b3, pw_b3 = "LFSR_EPI" in b3_ops, "LFSR_ROWGEMM" in b3_ops
         cls_spec = {   # class -> (kernel, bound, bytes, flop)
-            # executed flops: stage 1 in Winograd F(2,5) form runs 6 products per 2 outputs instead of 10 (x 0.6; LFSR_EPI=direct: x 1.0)
-            "epiconv": ("k_epi_wino5 (both EPI passes: 1xA^2 conv 64->32 in F(2,5) form, LReLU, 1x1 32->160, LReLU, PixelShuffle1D; DistgSSR.py:91-97,108)", "mfma",
-                        (64 + 64) * npx * 4, 2 * (0.524e9 * (1.0 if os.environ.get("LFSR_EPI", "")[:1] == "d" else 0.6) + 0.052e9) * B),
-            "pointwise": ("fuse.0 144->64 + LReLU (DistgSSR.py:98-100,109)", "hbm", (144 + 64) * npx * 4, 0.472e9 * B),
+            # executed flops: stage 1 in Winograd F(2,5) form runs 6 products per 2 outputs instead of 10 (x 0.6; LFSR_EPI=direct: x 1.0); in the three-term bf16 form the
+            # direct sums run as six bf16 products each (x 6 on the bf16 pipe)
+            "epiconv": (("k_epi_b3 (both EPI passes, direct form, fp32 operands as three exact bf16 terms: six bf16 MFMA products per fp32 product; DistgSSR.py:91-97,108)", "mfma-bf16x3",
+                         (64 + 64) * npx * 4, 6 * 2 * (0.524e9 + 0.052e9) * B) if epi_b3 else
+                        ("k_epi_wino5 (both EPI passes: 1xA^2 conv 64->32 in F(2,5) form, LReLU, 1x1 32->160, LReLU, PixelShuffle1D; DistgSSR.py:91-97,108)", "mfma",
+                         (64 + 64) * npx * 4, 2 * (0.524e9 * (1.0 if os.environ.get("LFSR_EPI", "")[:1] == "d" else 0.6) + 0.052e9) * B)),
+            "pointwise": ("fuse.0 144->64 + LReLU (DistgSSR.py:98-100,109)" + (" on k_rowgemm_b3 (three-term bf16 operands, 144 of 160 operand columns valid)" if pw_b3 else ""), "hbm",
+                          (144 + 64) * npx * 4, 0.472e9 * B),
             "angconv": ("k_ang_fused (AngConv.0 + LReLU + AngConv.2 + LReLU + PixelShuffle(A); DistgSSR.py:84-90)", "hbm", (64 + 16) * npx * 4, 0.065e9 * B),
             "init_conv": ("k_initconv (SAI2MacPI + 3x3 1->64; DistgSSR.py:22,31-32)", "hbm", (1 + 64) * npx * 4, 0.029e9 * B),
             "upsample_head": ("k_head<4> (MacPI2SAI + folded 64->16 1x1 + PixelShuffle(4) + bilinear skip; DistgSSR.py:24-35)", "hbm",
@@ -587,6 +615,9 @@ def bench_infer(args, rank, world, dev, dist):
                  "TBps": nbytes / us / 1e6, "TFLOPs": flop / us / 1e6}
             if bound == "hbm":
                 e.update(achieved=e["TBps"], unit="TB/s", frac=e["TBps"] / HBM_PEAK_TBPS, frac_of_copy=e["TBps"] / HBM_COPY_TBPS)
+            elif bound == "mfma-bf16x3":
+                e.update(achieved=e["TFLOPs"], unit="TFLOP/s (bf16 products executed)", frac=max(e["TFLOPs"] / BF16_MFMA_PEAK_TFLOPS, e["TBps"] / HBM_PEAK_TBPS),
+                         f32_equivalent_TFLOPs=e["TFLOPs"] / 6.0)
             else:
                 e.update(achieved=e["TFLOPs"], unit="TFLOP/s", frac=e["TFLOPs"] / FP32_MFMA_PEAK_TFLOPS)
             classes.append(e)

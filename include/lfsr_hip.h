@@ -348,15 +348,19 @@ int lfsr_internet_forward(lfsr_internet* ctx, const float* x, float* out, int B,
  * autograd in train.py:256-264).  Raw PyTorch-layout weights in (the entry points pack what their kernels read into the workspace), raw-layout weight
  * gradients out (overwritten); dx (pixels, 64) VCL is ACCUMULATED into (the block input receives gradients from four branches).
  * AngConv: y = PixelShuffle_A(lrelu(W2 . a16)), a16 = lrelu(W0 (*) x).  dy: dLoss/dy, 16 channels at dy_choff of a VCL buffer of row stride dy_stride;
- * x: the block input (pixels, 64) VCL; a16: the stage-1 activation lfsr_angconv_fwd left in its `tmp` argument ((B h w), 16); w0 (16,64,A,A), w2 (16 A^2,16,1,1). */
+ * y: the branch output as lfsr_angconv_fwd wrote it (its signs are the LeakyReLU' mask of stage 2), or NULL when dy already is the gradient at the stage-2
+ * pre-activation (what lfsr_pointwise_dgrad with act = the concat buffer leaves); x: the block input (pixels, 64) VCL; a16: the stage-1 activation
+ * lfsr_angconv_fwd left in its `tmp` argument ((B h w), 16); w0 (16,64,A,A), w2 (16 A^2,16,1,1). */
 size_t lfsr_angconv_bwd_workspace_floats(int B, int A, int h, int w);
-int lfsr_angconv_bwd(const float* dy, int dy_stride, int dy_choff, const float* x, const float* a16, const float* w0, const float* w2,
-                     float* dx, float* dw0, float* dw2, float* workspace, size_t workspace_floats, int B, int A, int h, int w, float slope, void* stream);
+int lfsr_angconv_bwd(const float* dy, int dy_stride, int dy_choff, const float* y, int y_stride, int y_choff, const float* x, const float* a16,
+                     const float* w0, const float* w2, float* dx, float* dw0, float* dw2, float* workspace, size_t workspace_floats,
+                     int B, int A, int h, int w, float slope, void* stream);
 /* EPIConv on the tensor and on its transpose (shared weights; both passes' weight gradients summed): dy holds dLoss/dy_h at choff_h and dLoss/dy_v at
- * choff_v (32 channels each); e_h / e_v: the stage-1 activations lfsr_epiconv_fwd(vertical = 0 / 1) left in `tmp` ((B A h w), 32);
- * w0 (32,64,1,A^2), w2 (32 A,32,1,1).  Odd angRes only (symmetric padding of the EPI line). */
+ * choff_v (32 channels each); y likewise the two outputs (or NULL, as above); e_h / e_v: the stage-1 activations lfsr_epiconv_fwd(vertical = 0 / 1) left
+ * in `tmp` ((B A h w), 32); w0 (32,64,1,A^2), w2 (32 A,32,1,1).  Odd angRes only (symmetric padding of the EPI line). */
 size_t lfsr_epiconv_hv_bwd_workspace_floats(int B, int A, int h, int w);
-int lfsr_epiconv_hv_bwd(const float* dy, int dy_stride, int choff_h, int choff_v, const float* x, const float* e_h, const float* e_v, const float* w0, const float* w2,
+int lfsr_epiconv_hv_bwd(const float* dy, int dy_stride, int choff_h, int choff_v, const float* y, int y_stride, int y_choff_h, int y_choff_v,
+                        const float* x, const float* e_h, const float* e_v, const float* w0, const float* w2,
                         float* dx, float* dw0, float* dw2, float* workspace, size_t workspace_floats, int B, int A, int h, int w, float slope, void* stream);
 
 /* ---- operator-level timing hooks (measurement aid; the reference times whole forwards only: check_efficiency_official.py:306-330) ----

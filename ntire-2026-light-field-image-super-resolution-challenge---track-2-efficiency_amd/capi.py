@@ -112,9 +112,9 @@ SIGNATURES = {
     "lfsr_comm_destroy": (c_i, [c_p]),
     "lfsr_allreduce": (c_i, [c_p, c_sz, c_p, c_p]),
     "lfsr_angconv_bwd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i]),
-    "lfsr_angconv_bwd": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_angconv_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_epiconv_hv_bwd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i]),
-    "lfsr_epiconv_hv_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_epiconv_hv_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_op_profile": (c_i, [c_i]),
     "lfsr_op_profile_read": (C.c_longlong, [C.c_char_p, c_sz]),
     "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
@@ -706,21 +706,24 @@ class RcclComm:
             self.comm = None
 
 
-def angconv_bwd(dy, dy_choff, x, a16, w0, w2, dx, B, A, h, w, slope=0.1):
-    """lfsr_angconv_bwd: dy / x / dx VCL tensors (pixels, stride); w0, w2 raw PyTorch layouts.  dx is accumulated into; -> (dw0, dw2)."""
+def angconv_bwd(dy, dy_choff, y, y_choff, x, a16, w0, w2, dx, B, A, h, w, slope=0.1):
+    """lfsr_angconv_bwd: dy / y / x / dx VCL tensors (pixels, stride); y = the forward output (None: dy is already the gradient at the stage-2 pre-activation);
+    w0, w2 raw PyTorch layouts.  dx is accumulated into; -> (dw0, dw2)."""
     lib = load()
     ws = torch.empty(lib.lfsr_angconv_bwd_workspace_floats(B, A, h, w), dtype=torch.float32, device=x.device)
     dw0, dw2 = torch.empty_like(w0), torch.empty_like(w2)
-    check(lib.lfsr_angconv_bwd(dev_ptr(dy), dy.shape[1], dy_choff, dev_ptr(x), dev_ptr(a16), dev_ptr(w0.contiguous()), dev_ptr(w2.contiguous()), dev_ptr(dx),
-                               dev_ptr(dw0), dev_ptr(dw2), dev_ptr(ws), ws.numel(), B, A, h, w, slope, stream_ptr()), "angconv_bwd")
+    check(lib.lfsr_angconv_bwd(dev_ptr(dy), dy.shape[1], dy_choff, _opt(y), y.shape[1] if y is not None else 0, y_choff, dev_ptr(x), dev_ptr(a16),
+                               dev_ptr(w0.contiguous()), dev_ptr(w2.contiguous()), dev_ptr(dx), dev_ptr(dw0), dev_ptr(dw2), dev_ptr(ws), ws.numel(), B, A, h, w, slope,
+                               stream_ptr()), "angconv_bwd")
     return dw0, dw2
 
 
-def epiconv_hv_bwd(dy, choff_h, choff_v, x, e_h, e_v, w0, w2, dx, B, A, h, w, slope=0.1):
+def epiconv_hv_bwd(dy, choff_h, choff_v, y, y_choff_h, y_choff_v, x, e_h, e_v, w0, w2, dx, B, A, h, w, slope=0.1):
     """lfsr_epiconv_hv_bwd (both passes, shared weights).  dx is accumulated into; -> (dw0, dw2)."""
     lib = load()
     ws = torch.empty(lib.lfsr_epiconv_hv_bwd_workspace_floats(B, A, h, w), dtype=torch.float32, device=x.device)
     dw0, dw2 = torch.empty_like(w0), torch.empty_like(w2)
-    check(lib.lfsr_epiconv_hv_bwd(dev_ptr(dy), dy.shape[1], choff_h, choff_v, dev_ptr(x), dev_ptr(e_h), dev_ptr(e_v), dev_ptr(w0.contiguous()), dev_ptr(w2.contiguous()),
-                                  dev_ptr(dx), dev_ptr(dw0), dev_ptr(dw2), dev_ptr(ws), ws.numel(), B, A, h, w, slope, stream_ptr()), "epiconv_hv_bwd")
+    check(lib.lfsr_epiconv_hv_bwd(dev_ptr(dy), dy.shape[1], choff_h, choff_v, _opt(y), y.shape[1] if y is not None else 0, y_choff_h, y_choff_v, dev_ptr(x),
+                                  dev_ptr(e_h), dev_ptr(e_v), dev_ptr(w0.contiguous()), dev_ptr(w2.contiguous()), dev_ptr(dx), dev_ptr(dw0), dev_ptr(dw2),
+                                  dev_ptr(ws), ws.numel(), B, A, h, w, slope, stream_ptr()), "epiconv_hv_bwd")
     return dw0, dw2

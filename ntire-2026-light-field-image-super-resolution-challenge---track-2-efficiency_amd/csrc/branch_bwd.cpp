@@ -9,6 +9,31 @@
 namespace {
 inline size_t al64(size_t v) { return (v + 63) & ~(size_t)63; }
 inline int pad32(int v) { return (v + 31) / 32 * 32; }
+
+// out[row][c] = dy[row][c] * LeakyReLU'(y[row][c]) for C channels (a multiple of 4) of strided VCL operands: the gradient at a branch's stage-2 pre-activation
+__global__ __launch_bounds__(256) void k_mask_lrelu(const float* __restrict__ dy, int dy_stride, int dy_choff, const float* __restrict__ y, int y_stride, int y_choff,
+                                                   float* __restrict__ out, int out_stride, int out_choff, long long rows, int C, float slope) {
+  const int c4 = C >> 2;
+  const long long total = rows * c4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(dy + r * dy_stride + dy_choff + c);
+    const float4 a = *reinterpret_cast<const float4*>(y + r * y_stride + y_choff + c);
+    *reinterpret_cast<float4*>(out + r * out_stride + out_choff + c) =
+        make_float4(a.x > 0.f ? g.x : g.x * slope, a.y > 0.f ? g.y : g.y * slope, a.z > 0.f ? g.z : g.z * slope, a.w > 0.f ? g.w : g.w * slope);
+  }
+}
+
+int mask_lrelu(const float* dy, int dy_stride, int dy_choff, const float* y, int y_stride, int y_choff, float* out, int out_stride, int out_choff, long long rows, int C,
+               float slope, hipStream_t st) {
+  if ((dy_stride | dy_choff | y_stride | y_choff | out_stride | out_choff | C) & 3 || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) & 15)) return LFSR_E_ARG;
+  unsigned grid = lfsr_blocks(rows * (C >> 2), 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(k_mask_lrelu, dim3(grid), dim3(256), 0, st, dy, dy_stride, dy_choff, y, y_stride, y_choff, out, out_stride, out_choff, rows, C, slope);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
 }  // namespace
 
 // AngConv: y = PixelShuffle_A(lrelu(W2 . a16)), a16 = lrelu(W0 (*) x) (A x A, stride A).  dcat: dLoss/dy inside a VCL buffer (16 channels at dc_choff).
@@ -107,7 +132,7 @@ size_t lfsr_branch_bwd_partial_floats(int B, int A, int h, int w) {
 }
 
 namespace {
-struct AngWs { float *w0p, *w0T, *w2T, *dA16, *P; size_t total; };
+struct AngWs { float *w0p, *w0T, *w2T, *dA16, *P, *dym; size_t total; };
 void ang_layout(int B, int A, int h, int w, float* base, AngWs& t) {
   const int AA = A * A;
   size_t o = 0;
@@ -117,9 +142,10 @@ void ang_layout(int B, int A, int h, int w, float* base, AngWs& t) {
   t.w2T = take((size_t)AA * pad32(16) * 16);
   t.dA16 = take((size_t)B * h * w * 16);
   t.P = take(lfsr_branch_bwd_partial_floats(B, A, h, w));
+  t.dym = take((size_t)B * AA * h * w * 16);
   t.total = o;
 }
-struct EpiWs { float *w0p, *w0T, *w2T, *dEh, *dEv, *P[4]; size_t total; };
+struct EpiWs { float *w0p, *w0T, *w2T, *dEh, *dEv, *P[4], *dym; size_t total; };
 void epi_layout(int B, int A, int h, int w, float* base, EpiWs& t) {
   const int AA = A * A;
   size_t o = 0;
@@ -130,6 +156,7 @@ void epi_layout(int B, int A, int h, int w, float* base, EpiWs& t) {
   t.dEh = take((size_t)B * A * h * w * 32);
   t.dEv = take((size_t)B * A * h * w * 32);
   for (int i = 0; i < 4; ++i) t.P[i] = take(lfsr_branch_bwd_partial_floats(B, A, h, w));
+  t.dym = take((size_t)B * AA * h * w * 64);
   t.total = o;
 }
 }  // namespace
@@ -143,10 +170,10 @@ size_t lfsr_angconv_bwd_workspace_floats(int B, int A, int h, int w) {
   return t.total;
 }
 
-int lfsr_angconv_bwd(const float* dy, int dy_stride, int dy_choff, const float* x, const float* a16, const float* w0, const float* w2,
+int lfsr_angconv_bwd(const float* dy, int dy_stride, int dy_choff, const float* y, int y_stride, int y_choff, const float* x, const float* a16, const float* w0, const float* w2,
                      float* dx, float* dw0, float* dw2, float* workspace, size_t workspace_floats, int B, int A, int h, int w, float slope, void* stream) {
   if (!dy || !x || !a16 || !w0 || !w2 || !dx || !dw0 || !dw2 || !workspace || B <= 0 || A <= 0 || A > 15 || !(A & 1) || h <= 0 || w <= 0) return LFSR_E_ARG;
-  if (dy_stride < dy_choff + 16 || ((uintptr_t)workspace & 15)) return LFSR_E_ARG;
+  if (dy_stride < dy_choff + 16 || (y && y_stride < y_choff + 16) || ((uintptr_t)workspace & 15)) return LFSR_E_ARG;
   if ((long long)B * A * A * h * w >= (1LL << 31) / 144) return LFSR_E_ARG;
   AngWs t;
   ang_layout(B, A, h, w, workspace, t);
@@ -157,6 +184,11 @@ int lfsr_angconv_bwd(const float* dy, int dy_stride, int dy_choff, const float* 
   if (!rc) rc = lfsr_pack_weight_T(w0, t.w0T, 16, 64, AA, 0, st);
   if (!rc) rc = lfsr_pack_weight_chunkT(w2, t.w2T, 16 * AA, 16, 16, 1, st);
   if (rc) return rc;
+  if (y) {   // dLoss/dy -> the gradient at the stage-2 pre-activation (inside the model the fuse.0 data gradient's LeakyReLU' epilogue has done this already)
+    rc = mask_lrelu(dy, dy_stride, dy_choff, y, y_stride, y_choff, t.dym, 16, 0, (long long)B * AA * h * w, 16, slope, st);
+    if (rc) return rc;
+    dy = t.dym; dy_stride = 16; dy_choff = 0;
+  }
   return lfsr_ang_branch_bwd(dy, dy_stride, dy_choff, x, a16, t.w0p, t.w0T, t.w2T, dx, dw0, dw2, t.dA16, t.P, B, A, h, w, slope, st);
 }
 
@@ -167,10 +199,11 @@ size_t lfsr_epiconv_hv_bwd_workspace_floats(int B, int A, int h, int w) {
   return t.total;
 }
 
-int lfsr_epiconv_hv_bwd(const float* dy, int dy_stride, int choff_h, int choff_v, const float* x, const float* e_h, const float* e_v, const float* w0, const float* w2,
+int lfsr_epiconv_hv_bwd(const float* dy, int dy_stride, int choff_h, int choff_v, const float* y, int y_stride, int y_choff_h, int y_choff_v,
+                        const float* x, const float* e_h, const float* e_v, const float* w0, const float* w2,
                         float* dx, float* dw0, float* dw2, float* workspace, size_t workspace_floats, int B, int A, int h, int w, float slope, void* stream) {
   if (!dy || !x || !e_h || !e_v || !w0 || !w2 || !dx || !dw0 || !dw2 || !workspace || B <= 0 || A <= 0 || A > 15 || !(A & 1) || h <= 0 || w <= 0) return LFSR_E_ARG;
-  if (dy_stride < choff_h + 32 || dy_stride < choff_v + 32 || ((uintptr_t)workspace & 15)) return LFSR_E_ARG;
+  if (dy_stride < choff_h + 32 || dy_stride < choff_v + 32 || (y && (y_stride < y_choff_h + 32 || y_stride < y_choff_v + 32)) || ((uintptr_t)workspace & 15)) return LFSR_E_ARG;
   if ((long long)B * A * A * h * w >= (1LL << 31) / 144) return LFSR_E_ARG;
   EpiWs t;
   epi_layout(B, A, h, w, workspace, t);
@@ -181,6 +214,13 @@ int lfsr_epiconv_hv_bwd(const float* dy, int dy_stride, int choff_h, int choff_v
   if (!rc) rc = lfsr_pack_weight_T(w0, t.w0T, 32, 64, AA, 0, st);
   if (!rc) rc = lfsr_pack_weight_chunkT(w2, t.w2T, 32 * A, 32, 32, 0, st);
   if (rc) return rc;
+  if (y) {
+    const long long npix = (long long)B * AA * h * w;
+    rc = mask_lrelu(dy, dy_stride, choff_h, y, y_stride, y_choff_h, t.dym, 64, 0, npix, 32, slope, st);
+    if (!rc) rc = mask_lrelu(dy, dy_stride, choff_v, y, y_stride, y_choff_v, t.dym, 64, 32, npix, 32, slope, st);
+    if (rc) return rc;
+    dy = t.dym; dy_stride = 64; choff_h = 0; choff_v = 32;
+  }
   return lfsr_epi_branch_bwd(dy, dy_stride, choff_h, choff_v, x, e_h, e_v, t.w0p, t.w0T, t.w2T, dx, dw0, dw2, t.dEh, t.dEv, t.P, B, A, h, w, slope, st);
 }
 

@@ -34,7 +34,7 @@ struct lfsr_distgssr {
   // batched repack (lfsr_distgssr_begin_batched_load): load_param records one descriptor per pack instead of launching it; finalize uploads the
   // table when it changed (parameter addresses are stable across optimizer steps) and launches one kernel per pack kind
   bool batch_mode = false;
-  std::vector<LfsrPackDesc> d_gen, d_c3, d_epi, uploaded;
+  std::vector<LfsrPackDesc> d_gen, d_c3, d_epi, d_epib, uploaded;
   LfsrPackDesc* table_dev = nullptr;
   size_t table_cap = 0;
   bool profiling = false;
@@ -114,7 +114,7 @@ void lfsr_distgssr_destroy(lfsr_distgssr* c) {
 int lfsr_distgssr_begin_batched_load(lfsr_distgssr* c) {
   if (!c) return LFSR_E_ARG;
   c->batch_mode = true;
-  c->d_gen.clear(); c->d_c3.clear(); c->d_epi.clear();
+  c->d_gen.clear(); c->d_c3.clear(); c->d_epi.clear(); c->d_epib.clear();
   return LFSR_OK;
 }
 
@@ -175,7 +175,11 @@ int lfsr_distgssr_load_param(lfsr_distgssr* c, const char* key, const float* dat
     if (c3) c->d_c3.push_back(LfsrPackDesc{data, dst, dst + LFSR_CONV3_DIRECT_FLOATS + LFSR_CONV3_WINO2_FLOATS, 0, 64, 64, 9, 64, 0, 0, 0});
     else {
       c->d_gen.push_back(LfsrPackDesc{data, dst, nullptr, 0, sl.O, sl.C, sl.T, pad32(sl.O), sl.perm, sl.ch, 0});
-      if (sl.O == 32 && sl.C == 64 && sl.T == 25 && sl.perm == 0) c->d_epi.push_back(LfsrPackDesc{dst, dst + 25 * 32 * 64, nullptr, 0, 32, 64, 25, 32, 0, 0, 0});
+      if (sl.O == 32 && sl.C == 64 && sl.T == 25 && sl.perm == 0) {
+        c->d_epi.push_back(LfsrPackDesc{dst, dst + 25 * 32 * 64, nullptr, 0, 32, 64, 25, 32, 0, 0, 0});
+        c->d_epib.push_back(LfsrPackDesc{dst, dst + 25 * 32 * 64 + LFSR_EPI_WINO_FLOATS, nullptr, 0, 32, 64, 25, 32, 0, 0, 0});     // the three bf16 planes (epi_b3.hip)
+      }
+      if (sl.O == 160 && sl.C == 32 && sl.T == 1 && sl.perm == 0) c->d_epib.push_back(LfsrPackDesc{dst, dst + 160 * 32, nullptr, 1, 160, 32, 1, 160, 0, 0, 0});
     }
     if (sl.kindT == 1 && c3) c->d_c3.push_back(LfsrPackDesc{data, tdst, tdst + LFSR_CONV3_DIRECT_FLOATS + LFSR_CONV3_WINO2_FLOATS, 0, 64, 64, 9, 64, 0, 0, 1});
     else if (sl.kindT == 1) c->d_gen.push_back(LfsrPackDesc{data, tdst, nullptr, 1, sl.O, sl.C, sl.T, pad32(sl.C), 0, 0, 1});
@@ -206,6 +210,7 @@ int lfsr_distgssr_finalize(lfsr_distgssr* c, void* stream) {
     std::vector<LfsrPackDesc> all(c->d_gen);
     all.insert(all.end(), c->d_c3.begin(), c->d_c3.end());
     all.insert(all.end(), c->d_epi.begin(), c->d_epi.end());
+    all.insert(all.end(), c->d_epib.begin(), c->d_epib.end());
     bool same = all.size() == c->uploaded.size();
     for (size_t i = 0; same && i < all.size(); ++i) same = memcmp(&all[i], &c->uploaded[i], sizeof(LfsrPackDesc)) == 0;
     if (!same) {
@@ -220,10 +225,11 @@ int lfsr_distgssr_finalize(lfsr_distgssr* c, void* stream) {
       hipError_t e = hipMemcpyAsync(c->table_dev, c->uploaded.data(), all.size() * sizeof(LfsrPackDesc), hipMemcpyHostToDevice, lfsr_stream(stream));
       if (e != hipSuccess) return LFSR_HIP_ERR(e);
     }
-    const int ng = (int)c->d_gen.size(), n3 = (int)c->d_c3.size(), ne = (int)c->d_epi.size();
+    const int ng = (int)c->d_gen.size(), n3 = (int)c->d_c3.size(), ne = (int)c->d_epi.size(), nb3 = (int)c->d_epib.size();
     int rcb = lfsr_pack_generic_batch(c->table_dev, ng, lfsr_stream(stream));
     if (!rcb) rcb = lfsr_pack_conv3_raw_wino4_batch(c->table_dev + ng, n3, lfsr_stream(stream));
     if (!rcb) rcb = lfsr_pack_epi_wino_batch(c->table_dev + ng + n3, ne, lfsr_stream(stream));   // reads the direct packs written by the first launch
+    if (!rcb) rcb = lfsr_pack_epi_b3_batch(c->table_dev + ng + n3 + ne, nb3, lfsr_stream(stream));  // likewise
     if (rcb) return rcb;
   }
   int rc = lfsr_fold_head(c->w("upsample.0.weight"), c->w("upsample.0.bias"), c->w("upsample.2.weight"),

@@ -1,0 +1,395 @@
+// EPIConv branch (model/SR/DistgSSR.py:91-97 and its transposed application :108) at angRes 5 on the bf16 MFMA pipe with fp32 operands carried EXACTLY as
+// three bf16 terms (default at A = 5; LFSR_EPI=wino keeps epi_fused.hip's fp32-MFMA Winograd F(2,5) kernel, LFSR_EPI=direct its direct fp32 form):
+//   t = lrelu(conv 1x25, stride (1,5), pad 10, 64->32);  y = lrelu(1x1 32->160);  PixelShuffle1D(5)       -- both passes (H and V) in one launch.
+// Arithmetic as in rowgemm_b3.hip: x = x0 + x1 + x2, w = w0 + w1 + w2 by truncation (the sums exact), the six products of order <= 2 as
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- closer to fp64 than an fp32 FMA chain (tests: test_epiconv*, test_b3_products_against_fp64).
+//
+// Formulation.  In VCL the 1x25 conv is a 5-tap 1-D conv along the EPI line over 5 views x 64 channels.  With N = SOURCE positions instead of output
+// positions the five taps share their B operands:  Z_dx[n][s] = sum_{v', c} W[5 dx + v'][n][c] X[v'][s][c]  for the 32 sources of a line (the two
+// padding positions on either side are zero and need no columns), then  t[x][n] = sum_dx Z_dx[n][x + dx - 2]  -- one shifted add of the five
+// accumulator tiles through a wave-private LDS tile.  So every input value is loaded ONCE (straight from global memory in B-operand order: lane =
+// source position, eight consecutive channels per k-group), split ONCE (5.5 VALU per element, in the shadow of the MFMAs) and feeds 5 taps x 32 outputs.
+// One wave = one EPI line = 80 accumulator registers; a persistent 512-thread block = 8 lines per group.  The weights arrive pre-split from the pack
+// (lfsr_pack_epi_b3) and are staged per (view, K step) in LDS, double-buffered behind ONE barrier per stage (30 KB per stage, straight copy);
+// stage 2 (1x1 32 -> 160) runs the same way from the LDS-resident planes of its weights, and its result goes out as 16-B stores per lane
+// (chunk = destination view = PixelShuffle1D).
+#include <stdlib.h>
+
+#include "lfsr_internal.h"
+
+namespace {
+
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+
+constexpr int EB_LINES = 8;
+constexpr int EB_STAGE_SLOTS = 5 * 3 * 4 * 32;              // 16-B slots of one (view, K step): [dx][plane][k-group][n]
+constexpr int EB_STAGE_BYTES = EB_STAGE_SLOTS * 16;         // 30720
+constexpr int EB_W2_SLOTS = 3 * 4 * 160;                    // [plane][k-group][n']
+constexpr int EB_W2_BYTES = EB_W2_SLOTS * 16;               // 30720
+constexpr int EB_TROW = 36;                                 // floats per row of a wave's exchange tile (144 B: 16 rows cover the 16 slots of a bank row once)
+constexpr int EB_SMEM = 2 * EB_STAGE_BYTES + EB_W2_BYTES + EB_LINES * 32 * EB_TROW * 4;     // 129024
+
+struct EpiB3Args {
+  const float* X; int x_stride; int x_choff; int x_bytes;
+  const uint4* W1p;     // [view 5][K step 2][EB_STAGE_SLOTS]  (lfsr_pack_epi_b3)
+  const uint4* W2p;     // [EB_W2_SLOTS]
+  float* Y; int y_stride; int choffH; int choffV;
+  float* TH; float* TV;   // optional (lines * len, 32): post-LeakyReLU stage-1 activations saved for the backward
+  int B, H, W;
+  int tilesH, tilesV;     // groups per pass
+  int tpiH, tpiV;         // > 0: groups ordered item by item (an item's horizontal groups, then its vertical ones)
+  float slope;
+};
+
+__device__ __forceinline__ unsigned eb_hi_pair(unsigned hi_src, unsigned lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
+__device__ __forceinline__ float eb_residual(float a) { return a - __uint_as_float(__float_as_uint(a) & 0xffff0000u); }   // exact
+
+// eight consecutive floats -> their three bf16 planes in MFMA operand order
+__device__ __forceinline__ void eb_split8(const f32x4e lo, const f32x4e hi, u32x4e& p0, u32x4e& p1, u32x4e& p2) {
+  const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  float r[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { r[j] = eb_residual(a[j]); q[j] = eb_residual(r[j]); }
+  p0 = u32x4e{eb_hi_pair(__float_as_uint(a[1]), __float_as_uint(a[0])), eb_hi_pair(__float_as_uint(a[3]), __float_as_uint(a[2])),
+              eb_hi_pair(__float_as_uint(a[5]), __float_as_uint(a[4])), eb_hi_pair(__float_as_uint(a[7]), __float_as_uint(a[6]))};
+  p1 = u32x4e{eb_hi_pair(__float_as_uint(r[1]), __float_as_uint(r[0])), eb_hi_pair(__float_as_uint(r[3]), __float_as_uint(r[2])),
+              eb_hi_pair(__float_as_uint(r[5]), __float_as_uint(r[4])), eb_hi_pair(__float_as_uint(r[7]), __float_as_uint(r[6]))};
+  p2 = u32x4e{eb_hi_pair(__float_as_uint(q[1]), __float_as_uint(q[0])), eb_hi_pair(__float_as_uint(q[3]), __float_as_uint(q[2])),
+              eb_hi_pair(__float_as_uint(q[5]), __float_as_uint(q[4])), eb_hi_pair(__float_as_uint(q[7]), __float_as_uint(q[6]))};
+}
+
+// asm MFMA with the accumulator tied (conv3x3_wino4b.hip: the builtin's register allocation may overlap vDst with a source partially)
+__device__ __forceinline__ void eb_mfma(f32x4e& c, const u32x4e a, const u32x4e b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// six products of one (A planes, B planes) pair into TWO accumulators alternately (two independent chains), smallest terms first
+__device__ __forceinline__ void eb_six2(f32x4e& c0, f32x4e& c1, const u32x4e a0, const u32x4e a1, const u32x4e a2,
+                                        const u32x4e x00, const u32x4e x01, const u32x4e x02, const u32x4e x10, const u32x4e x11, const u32x4e x12) {
+  eb_mfma(c0, a2, x00); eb_mfma(c1, a2, x10);
+  eb_mfma(c0, a0, x02); eb_mfma(c1, a0, x12);
+  eb_mfma(c0, a1, x01); eb_mfma(c1, a1, x11);
+  eb_mfma(c0, a1, x00); eb_mfma(c1, a1, x10);
+  eb_mfma(c0, a0, x01); eb_mfma(c1, a0, x11);
+  eb_mfma(c0, a0, x00); eb_mfma(c1, a0, x10);
+}
+
+__global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* const sW = smem_raw;                                   // [2][EB_STAGE_BYTES]
+  unsigned char* const sW2 = smem_raw + 2 * EB_STAGE_BYTES;             // [EB_W2_BYTES]
+  float* const sT = reinterpret_cast<float*>(smem_raw + 2 * EB_STAGE_BYTES + EB_W2_BYTES);   // [8 waves][32][EB_TROW]
+  constexpr int A = 5;
+  constexpr int EOOB = (int)0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int HW = p.H * p.W;
+  const int ngroups = p.tilesH + p.tilesV;
+  // consecutive workgroups go to consecutive XCDs: the blocks of one XCD walk a contiguous range of groups (both passes of an item share an L2)
+  const int nb = (int)gridDim.x;
+  const int vb = (nb & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
+
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+
+  // ---- group geometry (block-uniform) and this wave's line ----
+  struct Line { int vert, base, len, vstride, pstride, choff; long long rowbase; int rowstep; };
+  auto line_of = [&](int grp) -> Line {
+    Line L;
+    int tile;
+    if (p.tpiH > 0) {
+      const int per = p.tpiH + p.tpiV, item = grp / per, r = grp - item * per;
+      L.vert = r >= p.tpiH;
+      tile = L.vert ? item * p.tpiV + (r - p.tpiH) : item * p.tpiH + r;
+    } else {
+      L.vert = grp >= p.tilesH;
+      tile = L.vert ? grp - p.tilesH : grp;
+    }
+    L.len = L.vert ? p.H : p.W;
+    const int across = L.vert ? p.W : p.H;
+    const int nlines = p.B * A * across;
+    L.vstride = L.vert ? A * HW : HW;
+    L.pstride = L.vert ? p.W : 1;
+    L.choff = L.vert ? p.choffV : p.choffH;
+    const int ln = tile * EB_LINES + wave;
+    L.base = -1; L.rowbase = 0; L.rowstep = 0;
+    if (grp < ngroups && ln < nlines) {
+      const int q = ln / across, o = ln - q * across;     // horizontal: q = b*A+u, o = y;  vertical: q = b*A+v, o = x
+      if (!L.vert) L.base = q * A * HW + o * p.W;
+      else { const int b = q / A, v = q - b * A; L.base = (b * A * A + v) * HW + o; }
+      // rows of the saved stage-1 matrix are ordered like the gather-GEMM's: (b*A+u, y, x) / (b*A+v, y, x)
+      L.rowbase = L.vert ? (long long)q * p.H * p.W + o : ((long long)q * p.H + o) * p.W;
+      L.rowstep = L.vert ? p.W : 1;
+    }
+    return L;
+  };
+
+  f32x4e xr[2][2];                      // raw input of the NEXT stage: [source tile nt][lo / hi four floats]
+  auto load_x = [&](const Line& L, int j) {   // stage j = 2 v' + ks of the line
+    const int vv = j >> 1, ks = j & 1;
+    const int soff = (vv * L.vstride * p.x_stride + 32 * ks) * 4;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int s = 16 * nt + l15;
+      const int off = (L.base >= 0 && s < L.len) ? ((L.base + s * L.pstride) * p.x_stride + p.x_choff + 8 * g) * 4 : EOOB;
+      xr[nt][0] = __builtin_bit_cast(f32x4e, __builtin_amdgcn_raw_buffer_load_b128(rsX, off, soff, 0));
+      xr[nt][1] = __builtin_bit_cast(f32x4e, __builtin_amdgcn_raw_buffer_load_b128(rsX, off == EOOB ? EOOB : off + 16, soff, 0));
+    }
+  };
+  uint4 wr[4];                          // weight slots of the NEXT stage (3.75 per thread)
+  auto load_w = [&](int j) {
+    const uint4* src = p.W1p + j * EB_STAGE_SLOTS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i;
+      wr[i] = idx < EB_STAGE_SLOTS ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_w = [&](int buf) {
+    uint4* dst = reinterpret_cast<uint4*>(sW + buf * EB_STAGE_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i;
+      if (idx < EB_STAGE_SLOTS) dst[idx] = wr[i];
+    }
+  };
+
+  int grp = vb;
+  if (grp >= ngroups) return;           // (block-uniform: before any barrier)
+  Line L = line_of(grp);
+  load_x(L, 0);
+  load_w(0);
+  {   // stage-2 weight planes: once per block
+    uint4 w2r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int idx = tid + 512 * i; w2r[i] = idx < EB_W2_SLOTS ? p.W2p[idx] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int idx = tid + 512 * i; if (idx < EB_W2_SLOTS) reinterpret_cast<uint4*>(sW2)[idx] = w2r[i]; }
+  }
+  store_w(0);
+  __syncthreads();
+  int cur = 0;
+  const int aoff = (g * 32 + l15) * 16;                 // this lane's A-operand slot inside a (dx, plane) block: k-group g, weight row l15 (+ 16 mt)
+  float* const sTw = sT + wave * 32 * EB_TROW;
+
+  for (;;) {
+    const int ngrp = grp + nb;
+    const bool more = ngrp < ngroups;   // (block-uniform)
+    const Line Ln = line_of(more ? ngrp : ngroups);     // (ngroups: an absent line, every access out of range)
+    f32x4e acc[5][2][2];
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) { acc[dx][mt][0] = f32x4e{0.f, 0.f, 0.f, 0.f}; acc[dx][mt][1] = acc[dx][mt][0]; }
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) asm volatile("s_nop 1" : "+v"(acc[dx][0][0]), "+v"(acc[dx][0][1]), "+v"(acc[dx][1][0]), "+v"(acc[dx][1][1]));
+
+#pragma unroll 1
+    for (int j = 0; j < 10; ++j) {
+      // this stage's input: split; then the next stage's requests fly under the MFMAs
+      u32x4e x0[2], x1[2], x2[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) eb_split8(xr[nt][0], xr[nt][1], x0[nt], x1[nt], x2[nt]);
+      if (j < 9) { load_x(L, j + 1); load_w(j + 1); }
+      else { load_x(Ln, 0); load_w(0); }
+      asm volatile("s_nop 4" : "+v"(x0[0]), "+v"(x1[0]), "+v"(x2[0]), "+v"(x0[1]), "+v"(x1[1]), "+v"(x2[1]));
+      const unsigned char* wb = sW + cur * EB_STAGE_BYTES + aoff;
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const u32x4e a0 = *reinterpret_cast<const u32x4e*>(wb + ((dx * 3 + 0) * 128 + 16 * mt) * 16);
+          const u32x4e a1 = *reinterpret_cast<const u32x4e*>(wb + ((dx * 3 + 1) * 128 + 16 * mt) * 16);
+          const u32x4e a2 = *reinterpret_cast<const u32x4e*>(wb + ((dx * 3 + 2) * 128 + 16 * mt) * 16);
+          eb_six2(acc[dx][mt][0], acc[dx][mt][1], a0, a1, a2, x0[0], x1[0], x2[0], x0[1], x1[1], x2[1]);
+        }
+      }
+      store_w(cur ^ 1);                 // (read last in the stage before this one: every wave has passed that stage's barrier)
+      __syncthreads();
+      cur ^= 1;
+    }
+
+    // ---- t[x][n] = sum_dx Z_dx[n][x + dx - 2]: the centre tap as it stands, the others shifted through the wave's LDS tile ----
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx)
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[dx][0][0]), "+v"(acc[dx][0][1]), "+v"(acc[dx][1][0]), "+v"(acc[dx][1][1]));
+    f32x4e tv[2][2];                    // [mt][nt]: channels 16 mt + 4 g .. + 3 of position 16 nt + l15
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { tv[mt][0] = acc[2][mt][0]; tv[mt][1] = acc[2][mt][1]; }
+#pragma unroll
+    for (int di = 0; di < 4; ++di) {
+      const int dx = di < 2 ? di : di + 1;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f32x4e*>(sTw + (16 * nt + l15) * EB_TROW + 16 * mt + 4 * g) = acc[dx][mt][nt];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int r = 16 * nt + l15 + dx - 2;
+        const bool ok = r >= 0 && r < 32;
+        const int rc = ok ? r : 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const f32x4e z = *reinterpret_cast<const f32x4e*>(sTw + rc * EB_TROW + 16 * mt + 4 * g);
+          tv[mt][nt] += ok ? z : f32x4e{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      float* tsave = L.vert ? p.TV : p.TH;
+      const bool save = tsave && L.base >= 0;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = tv[mt][nt][r]; tv[mt][nt][r] = v >= 0.f ? v : v * p.slope; }
+          const int pos = 16 * nt + l15;
+          *reinterpret_cast<f32x4e*>(sTw + pos * EB_TROW + 16 * mt + 4 * g) = tv[mt][nt];
+          if (save && pos < L.len) *reinterpret_cast<f32x4e*>(tsave + (L.rowbase + (long long)pos * L.rowstep) * 32 + 16 * mt + 4 * g) = tv[mt][nt];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- stage 2: y[n'][x] = lrelu(sum_k W2[n'][k] t[x][k]), K = 32 = one K step; B operand = the t rows (lane: position, k-group g) ----
+    u32x4e t0[2], t1[2], t2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float* tp = sTw + (16 * nt + l15) * EB_TROW + 8 * g;
+      eb_split8(*reinterpret_cast<const f32x4e*>(tp), *reinterpret_cast<const f32x4e*>(tp + 4), t0[nt], t1[nt], t2[nt]);
+    }
+    asm volatile("s_nop 4" : "+v"(t0[0]), "+v"(t1[0]), "+v"(t2[0]), "+v"(t0[1]), "+v"(t1[1]), "+v"(t2[1]));
+    const unsigned char* w2b = sW2 + (g * 160 + l15) * 16;
+#pragma unroll
+    for (int mp = 0; mp < 5; ++mp) {    // destination view = chunk mp: its 32 channels = weight-row tiles 2 mp, 2 mp + 1
+      f32x4e o[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { o[h][0] = f32x4e{0.f, 0.f, 0.f, 0.f}; o[h][1] = o[h][0]; }
+      asm volatile("s_nop 1" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[1][0]), "+v"(o[1][1]));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int mt2 = 2 * mp + h;
+        const u32x4e a0 = *reinterpret_cast<const u32x4e*>(w2b + ((0 * 4) * 160 + 16 * mt2) * 16);
+        const u32x4e a1 = *reinterpret_cast<const u32x4e*>(w2b + ((1 * 4) * 160 + 16 * mt2) * 16);
+        const u32x4e a2 = *reinterpret_cast<const u32x4e*>(w2b + ((2 * 4) * 160 + 16 * mt2) * 16);
+        eb_six2(o[h][0], o[h][1], a0, a1, a2, t0[0], t1[0], t2[0], t0[1], t1[1], t2[1]);
+      }
+      asm volatile("s_nop 15\n\ts_nop 15" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[1][0]), "+v"(o[1][1]));
+      if (L.base >= 0) {
+        const long long dview = (long long)L.base + (long long)mp * L.vstride;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int pos = 16 * nt + l15;
+          if (pos < L.len) {
+            float* yp = p.Y + (dview + (long long)pos * L.pstride) * p.y_stride + L.choff + 4 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              f32x4e v = o[h][nt];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * p.slope;
+              *reinterpret_cast<f32x4e*>(yp + 16 * h) = v;
+            }
+          }
+        }
+      }
+    }
+    if (!more) break;
+    grp = ngrp;
+    L = Ln;
+  }
+}
+
+// ---- pack: the three bf16 planes of both stages' weights in exactly the order the kernel stages / reads them ----
+__device__ __forceinline__ void eb_planes8(const float* src, uint4& p0, uint4& p1, uint4& p2) {
+  unsigned h0[8], h1[8], h2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = src[j];
+    const float r = eb_residual(a), q = eb_residual(r);
+    h0[j] = __float_as_uint(a) >> 16; h1[j] = __float_as_uint(r) >> 16; h2[j] = __float_as_uint(q) >> 16;
+  }
+  p0 = make_uint4(h0[0] | (h0[1] << 16), h0[2] | (h0[3] << 16), h0[4] | (h0[5] << 16), h0[6] | (h0[7] << 16));
+  p1 = make_uint4(h1[0] | (h1[1] << 16), h1[2] | (h1[3] << 16), h1[4] | (h1[5] << 16), h1[6] | (h1[7] << 16));
+  p2 = make_uint4(h2[0] | (h2[1] << 16), h2[2] | (h2[3] << 16), h2[4] | (h2[5] << 16), h2[6] | (h2[7] << 16));
+}
+
+// kind 0: w1 direct pack [tap 5 dx + v'][n 32][c 64] -> [v'][ks][dx][plane][g][n] slots;  kind 1: w2 direct pack [n' 160][k 32] -> [plane][g][n'] slots
+__device__ __forceinline__ void eb_pack_one(const float* __restrict__ src, uint4* __restrict__ dst, int kind, int i) {
+  uint4 p0, p1, p2;
+  if (kind == 0) {
+    if (i >= 5 * 2 * 5 * 4 * 32) return;             // (v', ks, dx, g, n)
+    const int n = i & 31, g = (i >> 5) & 3, dx = (i >> 7) % 5, r = (i >> 7) / 5, ks = r & 1, v = r >> 1;
+    eb_planes8(src + ((5 * dx + v) * 32 + n) * 64 + 32 * ks + 8 * g, p0, p1, p2);
+    uint4* o = dst + (v * 2 + ks) * EB_STAGE_SLOTS + (dx * 3 * 4 + g) * 32 + n;
+    o[0] = p0; o[4 * 32] = p1; o[8 * 32] = p2;
+  } else {
+    if (i >= 4 * 160) return;                         // (g, n')
+    const int n = i % 160, g = i / 160;
+    eb_planes8(src + n * 32 + 8 * g, p0, p1, p2);
+    uint4* o = dst + g * 160 + n;
+    o[0] = p0; o[4 * 160] = p1; o[8 * 160] = p2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack_epi_b3(const float* __restrict__ src, uint4* __restrict__ dst, int kind) {
+  eb_pack_one(src, dst, kind, blockIdx.x * 256 + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_pack_epi_b3_batch(const LfsrPackDesc* __restrict__ tab) {
+  const LfsrPackDesc d = tab[blockIdx.y];
+  eb_pack_one(d.src, reinterpret_cast<uint4*>(d.dst), d.kind, blockIdx.x * 256 + threadIdx.x);
+}
+
+}  // namespace
+
+// kind 0: EPIConv.0 (direct pack -> LFSR_EPI_B3_W1_FLOATS), kind 1: EPIConv.2 (direct pack -> LFSR_EPI_B3_W2_FLOATS)
+int lfsr_pack_epi_b3(const float* direct_packed, float* out, int kind, hipStream_t st) {
+  if (!direct_packed || !out || (kind != 0 && kind != 1) || ((uintptr_t)out & 15)) return LFSR_E_ARG;
+  hipLaunchKernelGGL(k_pack_epi_b3, dim3(kind == 0 ? 25 : 3), dim3(256), 0, st, direct_packed, reinterpret_cast<uint4*>(out), kind);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+int lfsr_pack_epi_b3_batch(const LfsrPackDesc* table_dev, int n, hipStream_t st) {
+  if (!table_dev || n <= 0) return n == 0 ? LFSR_OK : LFSR_E_ARG;
+  hipLaunchKernelGGL(k_pack_epi_b3_batch, dim3(25, (unsigned)n), dim3(256), 0, st, table_dev);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
+// LFSR_E_ARG = not covered (the caller keeps epi_fused.hip's fp32-MFMA kernels)
+int lfsr_epi_b3_launch(const float* x, int x_stride, int x_choff, const float* w1_planes, const float* w2_planes, float* y, int y_stride,
+                       int choffH, int choffV, float* t_h, float* t_v, int B, int A, int h, int w, int which, float slope, hipStream_t st) {
+  if (A != 5 || h > 32 || w > 32 || h <= 0 || w <= 0 || B <= 0) return LFSR_E_ARG;
+  if ((x_stride | x_choff | y_stride | choffH | choffV) & 3) return LFSR_E_ARG;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w1_planes | (uintptr_t)w2_planes | (uintptr_t)t_h | (uintptr_t)t_v) & 15) return LFSR_E_ARG;
+  if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x
+  static std::atomic<bool> attr_set[64];
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_epi_b3), hipFuncAttributeMaxDynamicSharedMemorySize, EB_SMEM);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    attr_set[dev] = true;
+  }
+  EpiB3Args p{};
+  p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.x_bytes = (int)((long long)B * A * A * h * w * x_stride * 4);
+  p.W1p = reinterpret_cast<const uint4*>(w1_planes); p.W2p = reinterpret_cast<const uint4*>(w2_planes);
+  p.Y = y; p.y_stride = y_stride; p.choffH = choffH; p.choffV = choffV; p.TH = t_h; p.TV = t_v;
+  p.B = B; p.H = h; p.W = w; p.slope = slope;
+  p.tilesH = (which & 1) ? (B * A * h + EB_LINES - 1) / EB_LINES : 0;
+  p.tilesV = (which & 2) ? (B * A * w + EB_LINES - 1) / EB_LINES : 0;
+  const int ngroups = p.tilesH + p.tilesV;
+  if (ngroups <= 0) return LFSR_E_ARG;
+  if (which == 3 && (A * h) % EB_LINES == 0 && (A * w) % EB_LINES == 0) { p.tpiH = A * h / EB_LINES; p.tpiV = A * w / EB_LINES; }
+  int grid = cus[dev];
+  if (grid > ngroups) grid = ngroups;
+  hipLaunchKernelGGL(k_epi_b3, dim3((unsigned)grid), dim3(512), EB_SMEM, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

@@ -509,6 +509,11 @@ int lfsr_pack_epi_wino(const float* w1_direct_packed, float* out, hipStream_t st
   return LFSR_OK;
 }
 
+bool lfsr_epi_use_b3() {
+  const char* esel = getenv("LFSR_EPI");
+  return !(esel && (esel[0] == 'w' || esel[0] == 'd' || esel[0] == 'f' || esel[0] == 'g'));     // wino | direct | f32 | gather select an fp32-MFMA form
+}
+
 static size_t epi_wino_smem() { return (size_t)(LINES * 36 * LROW + 6 * 32 * LROW) * 4 + (LINES + 4) * 4 + (size_t)5 * 32 * TROW * 4; }
 
 size_t lfsr_epi_fused_smem(int A) {
@@ -524,6 +529,11 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   LfsrOpTimer op_t("epi_fused", B, h * w, st);
   // which: 1 = horizontal only, 2 = vertical only, 3 = both
   if (!lfsr_epi_fused_ok(A, h, w)) return LFSR_E_ARG;
+  if (A == 5 && lfsr_epi_use_b3()) {   // default at angRes 5: epi_b3.hip (exact three-term bf16 operands on the bf16 MFMA pipe); LFSR_EPI=wino | direct: this file's fp32-MFMA kernels
+    const int rc = lfsr_epi_b3_launch(x, x_stride, x_choff, w1_packed + 25 * 32 * 64 + LFSR_EPI_WINO_FLOATS, w2_packed + 160 * 32, y, y_stride, choffH, choffV,
+                                      t_h, t_v, B, A, h, w, which, slope, st);
+    if (rc != LFSR_E_ARG) return rc;
+  }
   if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x
   static std::atomic<bool> attr_set[64];
   int dev = 0;

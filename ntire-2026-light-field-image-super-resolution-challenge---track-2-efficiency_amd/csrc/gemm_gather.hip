@@ -171,7 +171,8 @@ extern "C" {
 size_t lfsr_packed_weight_floats(int O, int C, int taps) {
   size_t f = (size_t)taps * (size_t)npad32(O) * (size_t)C;
   if (O == 64 && C == 64 && taps == 9) f += LFSR_CONV3_WINO_FLOATS;   // 3x3 64->64: the Winograd-domain copy follows the direct pack
-  if (O == 32 && C == 64 && taps == 25) f += LFSR_EPI_WINO_FLOATS;    // EPIConv.0 at angRes 5: its F(2,5) copy follows the direct pack
+  if (O == 32 && C == 64 && taps == 25) f += LFSR_EPI_WINO_FLOATS + LFSR_EPI_B3_W1_FLOATS;    // EPIConv.0 at angRes 5: its F(2,5) copy and its three bf16 planes (epi_b3.hip) follow the direct pack
+  if (O == 160 && C == 32 && taps == 1) f += LFSR_EPI_B3_W2_FLOATS;   // EPIConv.2 at angRes 5: its three bf16 planes follow the direct pack
   return f;
 }
 
@@ -190,7 +191,11 @@ int lfsr_pack_conv_weight_m(const float* w, float* packed, int O, int C, int tap
   hipLaunchKernelGGL(k_pack_weight, dim3(lfsr_blocks(total, 256)), dim3(256), 0, lfsr_stream(stream), w, packed, O, C, taps, npad32(O), perm, ch);
   LFSR_CHECK_LAUNCH();
   if (O == 64 && C == 64 && taps == 9 && perm == 0) return lfsr_pack_wino_m(packed, packed + LFSR_CONV3_DIRECT_FLOATS, mask, lfsr_stream(stream));
-  if (O == 32 && C == 64 && taps == 25 && perm == 0) return lfsr_pack_epi_wino(packed, packed + 25 * 32 * 64, lfsr_stream(stream));
+  if (O == 32 && C == 64 && taps == 25 && perm == 0) {
+    const int rc = lfsr_pack_epi_wino(packed, packed + 25 * 32 * 64, lfsr_stream(stream));
+    return rc ? rc : lfsr_pack_epi_b3(packed, packed + 25 * 32 * 64 + LFSR_EPI_WINO_FLOATS, 0, lfsr_stream(stream));
+  }
+  if (O == 160 && C == 32 && taps == 1 && perm == 0) return lfsr_pack_epi_b3(packed, packed + 160 * 32, 1, lfsr_stream(stream));
   return LFSR_OK;
 }
 

@@ -90,6 +90,15 @@ int lfsr_ang_fused_launch(const float* x, int x_stride, int x_choff, const float
                           int y_stride, int y_choff, int B, int A, int h, int w, float slope, hipStream_t st);
 // epi_fused.hip: Winograd F(2,5) pack of an EPIConv.0 weight (O = 32, C = 64, taps = 25 = 5 x 5): LFSR_EPI_WINO_FLOATS after the direct pack
 #define LFSR_EPI_WINO_FLOATS (5 * 6 * 32 * 64)
+// epi_b3.hip: the three bf16 planes of the EPI branch's weights in the order k_epi_b3 stages them: after the F(2,5) copy of EPIConv.0 (O = 32, C = 64, taps = 25)
+// and after the direct pack of EPIConv.2 (O = 160, C = 32, taps = 1), both 16-B aligned
+#define LFSR_EPI_B3_W1_FLOATS (25 * 32 * 64 * 3 / 2)
+#define LFSR_EPI_B3_W2_FLOATS (160 * 32 * 3 / 2)
+bool lfsr_epi_use_b3();     // (epi_fused.hip) LFSR_EPI unset: the three-term bf16 kernel at angRes 5
+int lfsr_pack_epi_b3(const float* direct_packed, float* out, int kind, hipStream_t st);              // kind 0: EPIConv.0, 1: EPIConv.2
+int lfsr_pack_epi_b3_batch(const LfsrPackDesc* table_dev, int n, hipStream_t st);                     // src = the direct pack, dst = its planes, kind as above
+int lfsr_epi_b3_launch(const float* x, int x_stride, int x_choff, const float* w1_planes, const float* w2_planes, float* y, int y_stride,
+                       int choffH, int choffV, float* t_h, float* t_v, int B, int A, int h, int w, int which, float slope, hipStream_t st);
 int lfsr_pack_epi_wino(const float* w1_direct_packed, float* out, hipStream_t st);
 // epi_fused.hip  (t_h / t_v: optional (B*A*h*w, 32) buffers receiving the post-LeakyReLU stage-1 activations for backward)
 bool lfsr_epi_fused_ok(int A, int h, int w);

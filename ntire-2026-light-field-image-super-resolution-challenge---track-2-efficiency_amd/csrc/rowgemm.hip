@@ -301,7 +301,7 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
   const char* rsel = getenv("LFSR_ROWGEMM");
   // the bias-free K = 64 / 128 linears (the transformers' projections) run on the bf16 MFMA pipe with their fp32 operands split EXACTLY into three bf16 terms
   // (rowgemm_b3.hip; error against fp64 below this file's fp32-MFMA kernel: tools/b3_accuracy.py); LFSR_ROWGEMM=f32 keeps the fp32-MFMA form (A/B runs), 128 its wide tiles
-  if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !bias && (K == 64 || K == 128)) {
+  if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !bias && (K == 64 || K == 128 || K == 144)) {
     const int rc = lfsr_rowgemm_b3_launch(x, x_stride, x_choff, K, w_packed, res, res_stride, res_choff, y, y_stride, y_choff, M, N, slope, st);
     if (rc != LFSR_E_ARG) return rc;
   }

@@ -56,7 +56,8 @@ __device__ __forceinline__ void b3_mfma(f32x4b& c, const u32x4b a, const u32x4b 
 
 // NB = 64: 256 threads (4 waves x 16 rows), up to three blocks per CU; NB = 128: 512 threads (8 waves x 16 rows), one block per CU -- the token rows are read and split
 // once per 128 output columns instead of once per 64 (there is no barrier in the tile loop, so eight waves of one block overlap as well as four waves of two)
-template <int K, bool LN = false, int NB = 64>
+// KV < K: operand rows hold KV valid values (fuse.0 of DistgSSR: KV = 144 in five K steps of 32): weight columns and x values k >= KV are taken as zero
+template <int K, bool LN = false, int NB = 64, int KV = K>
 __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
   constexpr int NTH = NB * 4, BMR = NB, NT = NB / 16;
   constexpr int KS = K / 32;                // K steps
@@ -74,8 +75,8 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
   // the block's weight panel: split into planes, 8 consecutive k per thread-iteration
   for (int i = tid; i < NB * (K / 8); i += NTH) {
     const int r = i / (K / 8), c = i - r * (K / 8);
-    const bool ok = n0 + r < p.N;
-    const float* src = p.Wp + (long long)(ok ? n0 + r : 0) * K + c * 8;
+    const bool ok = n0 + r < p.N && c * 8 < KV;
+    const float* src = p.Wp + (long long)(ok ? n0 + r : 0) * KV + (ok ? c * 8 : 0);
     float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     if (!ok) { lo = make_float4(0.f, 0.f, 0.f, 0.f); hi = lo; }
     u32x4b w0, w1, w2;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offL + (32 * s + 4 * e) * 4, s4, 0));
+        f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offL + (32 * s + 4 * e) * 4, s4, 0));
+        if constexpr (KV < K) if (32 * s + 32 > KV && 32 * s + 8 * g >= KV) v = f32x4g{0.f, 0.f, 0.f, 0.f};     // (the neighbouring row's values: finite, but not ours)
         xr[s][e] = make_float4(v.x, v.y, v.z, v.w);
       }
     if constexpr (LN) if (do_ln && p.pe) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
   }
 }
 
-template <int K, bool LN = false, int NB = 64>
+template <int K, bool LN = false, int NB = 64, int KV = K>
 int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
   constexpr int smem = 3 * NB * K * 2;
   constexpr int per_cu = NB == 128 ? 1 : LN ? 2 : (smem <= 52 * 1024 ? 3 : 2);      // (the LN form of K = 128 needs 189 VGPRs: two 256-thread blocks per CU)
@@ -217,7 +219,7 @@ int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm_b3<K, LN, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rowgemm_b3<K, LN, NB, KV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
@@ -227,7 +229,7 @@ int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
   if (gx > 8) gx &= ~7;
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = (int)ntiles;
-  hipLaunchKernelGGL((k_rowgemm_b3<K, LN, NB>), dim3((unsigned)gx, (unsigned)nby), dim3(NB * 4), smem, st, p);
+  hipLaunchKernelGGL((k_rowgemm_b3<K, LN, NB, KV>), dim3((unsigned)gx, (unsigned)nby), dim3(NB * 4), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
@@ -248,6 +250,7 @@ int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, con
   switch (K) {
     case 64: return wide ? launch_b3<64, false, 128>(p, st) : launch_b3<64>(p, st);
     case 128: return wide ? launch_b3<128, false, 128>(p, st) : launch_b3<128>(p, st);
+    case 144: return launch_b3<160, false, 64, 144>(p, st);      // DistgSSR's fuse.0 (DistgSSR.py:99): 144 valid of 160 operand columns
     default: return LFSR_E_ARG;
   }
 }

@@ -98,7 +98,7 @@ def test_angconv_bwd_vs_autograd(B, A, h, w):
     capi.angconv(xv, capi.pack_conv_weight(w0.cuda()), capi.pack_conv_weight(w2.cuda(), perm=1, ch=16), B, A, h, w, 0.1, out, 0, tmp=a16)
     assert float((capi.vcl_to_nchw(out, B, 16, A, h, w, 1).cpu() - y_ref.detach()).abs().max()) <= 1e-4
     dxv = capi.nchw_to_vcl(dx0.cuda(), A, 1)
-    dw0, dw2 = capi.angconv_bwd(capi.nchw_to_vcl(dy.cuda(), A, 1), 0, xv, a16, w0.cuda(), w2.cuda(), dxv, B, A, h, w)
+    dw0, dw2 = capi.angconv_bwd(capi.nchw_to_vcl(dy.cuda(), A, 1), 0, out, 0, xv, a16, w0.cuda(), w2.cuda(), dxv, B, A, h, w)
     assert _rel(capi.vcl_to_nchw(dxv, B, 64, A, h, w, 1).cpu() - dx0, xr.grad) <= 1e-4
     assert _rel(dw0.cpu(), w0r.grad) <= 1e-4
     assert _rel(dw2.cpu(), w2r.grad) <= 1e-4
@@ -135,7 +135,7 @@ def test_epiconv_hv_bwd_vs_autograd(B, A, h, w):
     capi.nchw_to_vcl(dyh.cuda(), A, 1, out=dyb, choff=8)
     capi.nchw_to_vcl(dyv.cuda(), A, 1, out=dyb, choff=48)
     dxv = capi.nchw_to_vcl(dx0.cuda(), A, 1)
-    dw0, dw2 = capi.epiconv_hv_bwd(dyb, 8, 48, xv, eh, ev, w0.cuda(), w2.cuda(), dxv, B, A, h, w)
+    dw0, dw2 = capi.epiconv_hv_bwd(dyb, 8, 48, out, 0, 32, xv, eh, ev, w0.cuda(), w2.cuda(), dxv, B, A, h, w)
     assert _rel(capi.vcl_to_nchw(dxv, B, 64, A, h, w, 1).cpu() - dx0, xr.grad) <= 1e-4
     assert _rel(dw0.cpu(), w0r.grad) <= 1e-4
     assert _rel(dw2.cpu(), w2r.grad) <= 1e-4

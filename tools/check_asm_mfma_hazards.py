@@ -1,11 +1,11 @@
 """The three-term bf16 kernels issue their MFMAs as asm statements, so the compiler pads no wait states around them.  This reads the ISA of those files and
 checks, for every v_mfma, that no VALU instruction within the WAIT issue slots in front of it writes one of its source registers, and that no VALU / LDS / VMEM
 instruction within WAIT slots behind the LAST mfma of an accumulator chain reads its destination (s_nop N counts N + 1 slots).
-usage: python tools/check_asm_mfma_hazards.py [file.hip ...]   (default: rowgemm_b3.hip ffn_b3.hip up_tail.hip conv3x3_wino4b.hip)"""
+usage: python tools/check_asm_mfma_hazards.py [file.hip ...]   (default: rowgemm_b3.hip ffn_b3.hip up_tail.hip epi_b3.hip)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = [d for d in os.listdir(ROOT) if d.endswith("_amd")][0] + "/csrc"
-files = sys.argv[1:] or ["rowgemm_b3.hip", "ffn_b3.hip", "up_tail.hip"]
+files = sys.argv[1:] or ["rowgemm_b3.hip", "ffn_b3.hip", "up_tail.hip", "epi_b3.hip"]
 NEED_BEFORE, NEED_AFTER = 2, 18
 
 def regs(tok):
