@@ -117,7 +117,8 @@ int lfsr_angconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
 
 /* EPIConv, DistgSSR.py:91-97 (horizontal: vertical = 0) and its transposed application DistgSSR.py:108
  * (vertical = 1, same weights): t = lrelu(conv 1xA^2 stride A pad A(A-1)/2 64->32);
- * y = lrelu(1x1 32->32*A) scattered by PixelShuffle1D(A).  tmp: (B*A*h*w*32) floats. */
+ * y = lrelu(1x1 32->32*A) scattered by PixelShuffle1D(A).  tmp: (B*A*h*w*32) floats; on return it holds the pass's stage-1 activation t, rows ordered
+ * (b*A+u, y, x) / (b*A+v, y, x) -- what lfsr_epiconv_hv_bwd takes as e_h / e_v. */
 int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_packed, const float* w2_packed,
                      float* tmp, float* y, int y_stride, int y_choff, int B, int A, int h, int w, int vertical,
                      float slope, void* stream);

@@ -306,7 +306,8 @@ int lfsr_epiconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
   if (!x || !w1_packed || !w2_packed || !y || B <= 0 || A <= 0 || h <= 0 || w <= 0) return LFSR_E_ARG;
   if (x_stride < x_choff + 64 || y_stride < y_choff + 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if (epi_use_fused(A, h, w) && !((y_stride | y_choff) & 3) && (long long)B * A * A * h * w * x_stride * 4 < (1LL << 31))   // (16-B output vectors, 32-bit offsets)
-    return lfsr_epi_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, y, y_stride, y_choff, y_choff, nullptr, nullptr, B, A, h, w, vertical ? 2 : 1, slope, lfsr_stream(stream));
+    return lfsr_epi_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, y, y_stride, y_choff, y_choff, vertical ? nullptr : tmp, vertical ? tmp : nullptr, B, A, h, w,
+                                 vertical ? 2 : 1, slope, lfsr_stream(stream));     // tmp (may be NULL here): receives the pass's stage-1 activation, as the gather path leaves it
   if (!tmp) return LFSR_E_ARG;
   return lfsr_epiconv_gather(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, y_choff, B, A, h, w, vertical, slope, lfsr_stream(stream));
 }

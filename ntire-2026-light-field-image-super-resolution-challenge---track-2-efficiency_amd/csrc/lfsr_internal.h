@@ -160,6 +160,10 @@ int lfsr_ffn_b3_presplit(const float* w1_packed, const float* w2_packed, int K1,
 int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,
                               float* o, int o_stride, int o_choff, int nheads, int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
                               int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, hipStream_t st);
+// win_attn_mfma.hip: 5 x 5 spatial window attention (LFT) on the matrix pipe; LFSR_E_ARG = geometry not covered
+int lfsr_win_attn_mfma_launch(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,
+                              float* o, int o_stride, int o_choff, int nheads, int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
+                              int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, hipStream_t st);
 
 // wgrad.hip
 int lfsr_wgrad_splits(int M, int ntaps, int K);

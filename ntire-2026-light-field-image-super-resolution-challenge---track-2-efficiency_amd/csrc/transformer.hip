@@ -337,6 +337,12 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
                                                bs0, bs1, bs2, n1, n2, st1, st2, l1, r1, l2, r2, clip2, lfsr_stream(stream));
       if (rc != LFSR_E_ARG) return rc;
     }
+    // 5 x 5 spatial windows (LFT's SpaTrans): tiles of 4 x 4 queries against the 8 x 8 keys around them on the matrix pipe (win_attn_mfma.hip)
+    if (hd == 16 && !(asel && asel[0] == 'v') && !getenv("LFSR_ATTN_L1")) {
+      const int rc = lfsr_win_attn_mfma_launch(q, q_stride, q_choff, k, k_stride, k_choff, v, v_stride, v_choff, o, o_stride, o_choff, nheads, ns0, ns1, ns2,
+                                               bs0, bs1, bs2, n1, n2, st1, st2, l1, r1, l2, r2, clip2, lfsr_stream(stream));
+      if (rc != LFSR_E_ARG) return rc;
+    }
   }
   // LDS-tiled path (hd 16, heads in pairs): stage the keys a tile of queries can see once; used when the staged tile fits
   if (hd == 16 && nheads % 2 == 0 && !getenv("LFSR_ATTN_L1")) {

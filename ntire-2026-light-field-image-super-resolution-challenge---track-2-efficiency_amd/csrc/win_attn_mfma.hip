@@ -1,0 +1,160 @@
+// Spatial window self-attention on the matrix pipe (model/SR/LFT.py:161-203: SpaTrans.gen_mask + nn.MultiheadAttention, 8 heads of 16, additive -inf mask
+// of the 5 x 5 window [i-2, i+3) x [j-2, min(j+3, clip)) -- the reference clamps the column window with h, LFT.py:168; configs[4] of BASELINE.json).
+//
+// A sequence is the (n1 x n2) token grid of one view image; a query sees at most 25 of its (up to 1024) keys.  The VALU kernel (transformer.hip:
+// k_window_attn_lds) walks those 25 keys per (query, head) with eight ds_read_b128 each and sits at its LDS-read limit.  Here a TILE of 16 queries =
+// a 4 x 4 block of tokens; the union of its windows is the 8 x 8 block of keys around it = four key tiles of 2 rows x 8 columns, and per (tile, head)
+//   S^T tile  = K_tile Q_tile^T        A = K [key = lane & 15][d = 4 g + r], B = Q [q = lane & 15][d = 4 g + r]           (v_mfma_f32_16x16x4_f32)
+//   softmax   over the 64 candidate keys of a query = over 16 registers and the four 16-lane groups (two wave shuffles); keys outside the query's own
+//             5 x 5 window (or outside the image) are -inf: 25 of 64 products are used, which still beats 25 scalar key walks by far
+//   O^T tile += V_tile^T P_tile^T       A = V^T [d = lane & 15][key = 4 g + r], B = P^T = the S^T accumulator registers as they stand
+// exactly as attn_mfma.hip does for EPIT's band.  One 256-thread block = one (sequence, strip of 8 query rows, head): the 12 key rows the strip can see
+// are staged once -- K [row][col][16] with the 16-B chunks rotated by the key index (row pitch 40 keys: the two rows of a key tile land on disjoint bank
+// groups), V^T [d][row][col] with a d pitch of 484 floats (the 16 lanes of an A-operand read hit 16 distinct 16-B slots) -- 60 KB, two blocks per CU.
+#include <math.h>
+
+#include "lfsr_internal.h"
+
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WA_ROWS = 12, WA_KP = 40, WA_VD = 484;                    // staged key rows, key-row pitch (keys), V^T pitch per d (floats)
+constexpr int WA_SMEM = (WA_ROWS * WA_KP * 16 + 16 * WA_VD) * 4;        // 61696
+
+struct WinAttnArgs {
+  const float* Q; int q_stride, q_choff;
+  const float* K; int k_stride, k_choff;
+  const float* V; int v_stride, v_choff;
+  float* O; int o_stride, o_choff;
+  int ns1, ns2; long long bs0, bs1, bs2;
+  int n1, n2; long long st1, st2;
+  int kmax;        // min(n2, clip2): first invalid key column
+  int nstrip, ntc; // strips of 8 query rows per sequence; 4-column query tiles per row
+  float scale;     // 1 / sqrt(16) * log2(e)
+};
+
+__global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const sK = smem;                                   // [12][40][16], chunk c of key kl at ((c + (kl >> 2)) & 3)
+  float* const sVt = smem + WA_ROWS * WA_KP * 16;           // [16][484]: [d][row * 40 + col]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int head = blockIdx.y;
+  int t = blockIdx.x;
+  const int strip = t % p.nstrip; t /= p.nstrip;
+  const int s2 = t % p.ns2; t /= p.ns2;
+  const int s1 = t % p.ns1;
+  const int s0 = t / p.ns1;
+  const long long base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
+  const int r0 = strip * 8 - 2;                             // token row of staged key row 0
+  const int ncol = 4 * p.ntc + 4;                           // staged key columns: token columns -2 .. 4 ntc + 1
+
+  // ---- stage K and V^T of this head for the 12 key rows (item = (key, 16-B chunk c of its 64-B head slice); keys outside the image are zeros) ----
+  for (int idx = tid; idx < WA_ROWS * ncol * 4; idx += 256) {
+    const int c = idx & 3, key = idx >> 2;
+    const int row = key / ncol, ci = key - row * ncol;
+    const int kr = r0 + row, kc = ci - 2;
+    f32x4q kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (kr >= 0 && kr < p.n1 && kc >= 0 && kc < p.n2) {
+      const long long pix = base + kr * p.st1 + kc * p.st2;
+      kv = *reinterpret_cast<const f32x4q*>(p.K + pix * p.k_stride + p.k_choff + head * 16 + 4 * c);
+      vv = *reinterpret_cast<const f32x4q*>(p.V + pix * p.v_stride + p.v_choff + head * 16 + 4 * c);
+    }
+    const int kl = row * WA_KP + ci;
+    *reinterpret_cast<f32x4q*>(sK + kl * 16 + (((c + (kl >> 2)) & 3) << 2)) = kv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sVt[(4 * c + j) * WA_VD + kl] = vv[j];
+  }
+  __syncthreads();
+
+  const int ntile = 2 * p.ntc;
+  for (int tile = wave; tile < ntile; tile += 4) {
+    const int al = tile / p.ntc, b = tile - al * p.ntc;     // tile row inside the strip (0 / 1), tile column
+    // this lane's query
+    const int qr = strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
+    const bool qok = qr < p.n1 && qc < p.n2;
+    const long long qpix = base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
+    f32x4q qb = *reinterpret_cast<const f32x4q*>(p.Q + qpix * p.q_stride + p.q_choff + head * 16 + 4 * g);
+    qb *= p.scale;
+    // registers r of a key tile kt hold key (row 4 al + 2 kt + (g >> 1), column 4 b + 4 (g & 1) + r) of the staged block
+    const int kc0 = 4 * b - 2 + 4 * (g & 1);               // token column of register 0
+    f32x4q S[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int krow = 4 * al + 2 * kt + (l15 >> 3);
+      const int kl = krow * WA_KP + 4 * b + (l15 & 7);
+      const f32x4q ka = *reinterpret_cast<const f32x4q*>(sK + kl * 16 + (((g + (kl >> 2)) & 3) << 2));
+      f32x4q acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qb.w, acc, 0, 0, 0);
+      const int kr = r0 + 4 * al + 2 * kt + (g >> 1);       // token row of this lane group's keys
+      const bool rok = (unsigned)kr < (unsigned)p.n1 && (unsigned)(kr - qr + 2) < 5u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kc = kc0 + r;
+        const bool ok = rok && (unsigned)kc < (unsigned)p.kmax && (unsigned)(kc - qc + 2) < 5u;
+        const float s = ok ? acc[r] : -INFINITY;
+        S[kt][r] = s;
+        m = fmaxf(m, s);
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float den = 0.f;
+    f32x4q o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4q pw;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pw[r] = __builtin_amdgcn_exp2f(S[kt][r] - m);       // base-2 softmax (q carries log2 e); exp2(-inf) = 0 on masked keys; an empty window gives NaN like softmax over an all -inf row
+        den += pw[r];
+      }
+      const f32x4q va = *reinterpret_cast<const f32x4q*>(sVt + l15 * WA_VD + (4 * al + 2 * kt + (g >> 1)) * WA_KP + 4 * b + 4 * (g & 1));
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, pw.x, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, pw.y, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, pw.z, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, pw.w, o, 0, 0, 0);
+    }
+    den += __shfl_xor(den, 16);
+    den += __shfl_xor(den, 32);
+    const float inv = 1.0f / den;
+    if (qok) *reinterpret_cast<f32x4q*>(p.O + qpix * p.o_stride + p.o_choff + head * 16 + 4 * g) = o * inv;
+  }
+}
+
+}  // namespace
+
+// LFSR_E_ARG = geometry not covered (the caller keeps the VALU kernels): heads of 16, the 5 x 5 window [t-2, t+3) in both directions, at most 36 staged key columns
+int lfsr_win_attn_mfma_launch(const float* q, int q_stride, int q_choff, const float* k, int k_stride, int k_choff, const float* v, int v_stride, int v_choff,
+                              float* o, int o_stride, int o_choff, int nheads, int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
+                              int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, hipStream_t st) {
+  if (l1 != 2 || r1 != 3 || l2 != 2 || r2 != 3 || n2 > 32 || n2 < 1 || n1 < 1 || nheads < 1 || nheads > 65535) return LFSR_E_ARG;
+  if ((q_stride | q_choff | k_stride | k_choff | v_stride | v_choff | o_stride | o_choff) & 3) return LFSR_E_ARG;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) return LFSR_E_ARG;
+  WinAttnArgs p{};
+  p.Q = q; p.q_stride = q_stride; p.q_choff = q_choff; p.K = k; p.k_stride = k_stride; p.k_choff = k_choff;
+  p.V = v; p.v_stride = v_stride; p.v_choff = v_choff; p.O = o; p.o_stride = o_stride; p.o_choff = o_choff;
+  p.ns1 = ns1; p.ns2 = ns2; p.bs0 = bs0; p.bs1 = bs1; p.bs2 = bs2; p.n1 = n1; p.n2 = n2; p.st1 = st1; p.st2 = st2;
+  const int clip = clip2 > 0 ? clip2 : n2;
+  p.kmax = n2 < clip ? n2 : clip;
+  p.nstrip = (n1 + 7) / 8; p.ntc = (n2 + 3) / 4;
+  p.scale = (1.0f / sqrtf(16.0f)) * 1.44269504088896340736f;
+  const long long nblk = (long long)ns0 * ns1 * ns2 * p.nstrip;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_win_attn_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, WA_SMEM);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(k_win_attn_mfma, dim3((unsigned)nblk, (unsigned)nheads), dim3(256), WA_SMEM, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}

@@ -82,6 +82,31 @@ def test_linear_and_ffn_sweep(monkeypatch):
         assert a[:, 2].max() <= 1.5 * a[:, 3].max(), k
 
 
+def test_fuse0_three_term_vs_fp32_kernel(monkeypatch):
+    """DistgSSR's fuse.0 (1x1 144 -> 64 + LeakyReLU, DistgSSR.py:99) on k_rowgemm_b3 with 144 of 160 operand columns valid, read out of a wider buffer whose
+    neighbouring rows hold NaN-free but LARGE values (the masked columns must not leak), against fp64 and the fp32-MFMA row-GEMM"""
+    rng = np.random.default_rng(144)
+    M = 5003
+    xw = (rng.standard_normal((M, 160)) * 1e3).astype(np.float32)          # row stride 160: columns 8 .. 151 are the operand, the rest is foreign data
+    xw[:, 8:152] = rng.standard_normal((M, 144)).astype(np.float32) + rng.standard_normal((M, 1)).astype(np.float32)
+    w = (rng.standard_normal((64, 144)) * 0.1).astype(np.float32)
+    lib = capi.load()
+    xd = dev(xw)
+    wp = capi.pack_conv_weight(dev(w.reshape(64, 144, 1, 1)))
+
+    def run():
+        y = torch.full((M, 64), float("nan"), device="cuda")
+        capi.check(lib.lfsr_pointwise_fwd(capi.dev_ptr(xd), 160, 8, 144, capi.dev_ptr(wp), None, capi.dev_ptr(y), 64, 0, M, 64, 0.1, capi.stream_ptr()), "pointwise")
+        return y.cpu().numpy().astype(np.float64)
+    pre = xw[:, 8:152].astype(np.float64) @ w.astype(np.float64).T
+    ref = np.where(pre >= 0, pre, 0.1 * pre)
+    yb, yf = both(run, monkeypatch)
+    eb, ef = np.abs(yb - ref), np.abs(yf - ref)
+    print(f"fuse.0: three-term mean {eb.mean():.2e} max {eb.max():.2e} | fp32 MFMA mean {ef.mean():.2e} max {ef.max():.2e}")
+    assert eb.max() < 1e-4 and eb.mean() <= 1.1 * ef.mean() and eb.max() <= 1.5 * ef.max()
+    assert not np.array_equal(yb, yf)
+
+
 @pytest.mark.parametrize("B,h,w", [(2, 32, 32), (1, 17, 32), (1, 32, 9)])
 def test_epi_branch_three_term_vs_fp32_kernel(B, h, w, monkeypatch):
     """both EPI passes (DistgSSR.py:91-97,108) at angRes 5, unit-variance input: error against fp64 of epi_b3.hip and of the fp32-MFMA Winograd kernel"""

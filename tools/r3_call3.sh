@@ -2,7 +2,7 @@
 # round 3, call 3: EPI branch on the three-term bf16 pipe: operator tests, accuracy sweep, whole-model tests, A/B bench in one process environment
 set -e
 mkdir -p gpurun_out/r3
-python -m pytest tests/test_gpu_b3_accuracy.py tests/test_gpu_bwd_ops.py "tests/test_gpu_distgssr.py" -x -q -m gpu -s > gpurun_out/r3/c3_tests.log 2>&1 || { tail -40 gpurun_out/r3/c3_tests.log; exit 1; }
+python -m pytest tests/test_gpu_b3_accuracy.py tests/test_gpu_bwd_ops.py tests/test_gpu_distgssr.py tests/test_gpu_lft.py -x -q -m gpu -s > gpurun_out/r3/c3_tests.log 2>&1 || { tail -40 gpurun_out/r3/c3_tests.log; exit 1; }
 grep -E "three-term|passed|failed|EPI branch" gpurun_out/r3/c3_tests.log | tail -12
 for sel in b3 wino b3 wino; do
   if [ $sel = wino ]; then export LFSR_EPI=wino; else unset LFSR_EPI; fi
