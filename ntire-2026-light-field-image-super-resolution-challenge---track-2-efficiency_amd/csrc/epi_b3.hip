@@ -124,8 +124,11 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
     return L;
   };
 
-  f32x4e xr[2][2];                      // raw input of the NEXT stage: [source tile nt][lo / hi four floats]
-  auto load_x = [&](const Line& L, int j) {   // stage j = 2 v' + ks of the line
+  // raw input, two stages deep ([source tile nt][lo / hi four floats]) and its planes, double-buffered: stage j's MFMAs read planes P(j & 1) while the raw values of
+  // stage j + 1 are split into the other set IN THEIR SHADOW (two slices pinned between MFMA groups) and the loads of stage j + 2 fly
+  f32x4e rawA[2][2], rawB[2][2];
+  u32x4e pA0[2], pA1[2], pA2[2], pB0[2], pB1[2], pB2[2];
+  auto load_x = [&](const Line& L, int j, f32x4e (&xr)[2][2]) {   // stage j = 2 v' + ks of the line
     const int vv = j >> 1, ks = j & 1;
     const int soff = (vv * L.vstride * p.x_stride + 32 * ks) * 4;
 #pragma unroll
@@ -157,7 +160,8 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
   int grp = vb;
   if (grp >= ngroups) return;           // (block-uniform: before any barrier)
   Line L = line_of(grp);
-  load_x(L, 0);
+  load_x(L, 0, rawA);
+  load_x(L, 1, rawB);
   load_w(0);
   {   // stage-2 weight planes: once per block
     uint4 w2r[4];
@@ -167,6 +171,8 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
     for (int i = 0; i < 4; ++i) { const int idx = tid + 512 * i; if (idx < EB_W2_SLOTS) reinterpret_cast<uint4*>(sW2)[idx] = w2r[i]; }
   }
   store_w(0);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) eb_split8(rawA[nt][0], rawA[nt][1], pA0[nt], pA1[nt], pA2[nt]);
   __syncthreads();
   int cur = 0;
   const int aoff = (g * 32 + l15) * 16;                 // this lane's A-operand slot inside a (dx, plane) block: k-group g, weight row l15 (+ 16 mt)
@@ -184,29 +190,48 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) asm volatile("s_nop 1" : "+v"(acc[dx][0][0]), "+v"(acc[dx][0][1]), "+v"(acc[dx][1][0]), "+v"(acc[dx][1][1]));
 
-#pragma unroll 1
-    for (int j = 0; j < 10; ++j) {
-      // this stage's input: split; then the next stage's requests fly under the MFMAs
-      u32x4e x0[2], x1[2], x2[2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) eb_split8(xr[nt][0], xr[nt][1], x0[nt], x1[nt], x2[nt]);
-      if (j < 9) { load_x(L, j + 1); load_w(j + 1); }
-      else { load_x(Ln, 0); load_w(0); }
-      asm volatile("s_nop 4" : "+v"(x0[0]), "+v"(x1[0]), "+v"(x2[0]), "+v"(x0[1]), "+v"(x1[1]), "+v"(x2[1]));
+    // one stage: MFMAs of stage j on the planes (u0, u1, u2); raw values rs (stage j + 1) split into (d0, d1, d2); loads of stage j + 2 into rd
+    auto stage = [&](int j, u32x4e (&u0)[2], u32x4e (&u1)[2], u32x4e (&u2)[2], f32x4e (&rs)[2][2], u32x4e (&d0)[2], u32x4e (&d1)[2], u32x4e (&d2)[2],
+                     f32x4e (&rd)[2][2]) {
+      if (j + 2 < 10) load_x(L, j + 2, rd);
+      else load_x(Ln, j + 2 - 10, rd);
+      load_w(j + 1 < 10 ? j + 1 : 0);
+      asm volatile("s_nop 4" : "+v"(u0[0]), "+v"(u1[0]), "+v"(u2[0]), "+v"(u0[1]), "+v"(u1[1]), "+v"(u2[1]));
       const unsigned char* wb = sW + cur * EB_STAGE_BYTES + aoff;
+      // A operands (the weights' planes of tap dx, row tile mt) one group ahead of their MFMAs
+      u32x4e af[2][3];
+      auto load_a = [&](int c, u32x4e (&a)[3]) {
+        const int dx = c >> 1, mt = c & 1;
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
+        for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const u32x4e*>(wb + ((dx * 3 + pl) * 128 + 16 * mt) * 16);
+      };
+      load_a(0, af[0]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const u32x4e a0 = *reinterpret_cast<const u32x4e*>(wb + ((dx * 3 + 0) * 128 + 16 * mt) * 16);
-          const u32x4e a1 = *reinterpret_cast<const u32x4e*>(wb + ((dx * 3 + 1) * 128 + 16 * mt) * 16);
-          const u32x4e a2 = *reinterpret_cast<const u32x4e*>(wb + ((dx * 3 + 2) * 128 + 16 * mt) * 16);
-          eb_six2(acc[dx][mt][0], acc[dx][mt][1], a0, a1, a2, x0[0], x1[0], x2[0], x0[1], x1[1], x2[1]);
+      for (int c = 0; c < 10; ++c) {
+        const int dx = c >> 1, mt = c & 1;
+        if (c + 1 < 10) load_a(c + 1, af[(c + 1) & 1]);
+        eb_six2(acc[dx][mt][0], acc[dx][mt][1], af[c & 1][0], af[c & 1][1], af[c & 1][2], u0[0], u1[0], u2[0], u0[1], u1[1], u2[1]);
+        // the next stage's split, one pair of values (11 VALU) behind each of the first eight MFMA groups: volatile asm statements keep their order, so "defining"
+        // the inputs here and "using" the outputs below fences the slice between two groups -- in the MFMAs' shadow instead of in a burst of its own
+        if (c < 8) {
+          const int nt = c >> 2, k = c & 3;
+          asm volatile("" : "+v"(rs[nt][k >> 1]));
+          const float a0f = rs[nt][k >> 1][(k & 1) * 2], a1f = rs[nt][k >> 1][(k & 1) * 2 + 1];
+          const float r0 = eb_residual(a0f), r1 = eb_residual(a1f), q0 = eb_residual(r0), q1 = eb_residual(r1);
+          d0[nt][k] = eb_hi_pair(__float_as_uint(a1f), __float_as_uint(a0f));
+          d1[nt][k] = eb_hi_pair(__float_as_uint(r1), __float_as_uint(r0));
+          d2[nt][k] = eb_hi_pair(__float_as_uint(q1), __float_as_uint(q0));
+          asm volatile("" : "+v"(d0[nt]), "+v"(d1[nt]), "+v"(d2[nt]));
         }
       }
       store_w(cur ^ 1);                 // (read last in the stage before this one: every wave has passed that stage's barrier)
       __syncthreads();
       cur ^= 1;
+    };
+#pragma unroll 1
+    for (int jj = 0; jj < 10; jj += 2) {
+      stage(jj, pA0, pA1, pA2, rawB, pB0, pB1, pB2, rawA);
+      stage(jj + 1, pB0, pB1, pB2, rawA, pA0, pA1, pA2, rawB);
     }
 
     // ---- t[x][n] = sum_dx Z_dx[n][x + dx - 2]: the centre tap as it stands, the others shifted through the wave's LDS tile ----

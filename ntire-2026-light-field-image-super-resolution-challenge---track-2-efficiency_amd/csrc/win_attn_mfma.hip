@@ -50,33 +50,65 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
   const int r0 = strip * 8 - 2;                             // token row of staged key row 0
   const int ncol = 4 * p.ntc + 4;                           // staged key columns: token columns -2 .. 4 ntc + 1
 
-  // ---- stage K and V^T of this head for the 12 key rows (item = (key, 16-B chunk c of its 64-B head slice); keys outside the image are zeros) ----
-  for (int idx = tid; idx < WA_ROWS * ncol * 4; idx += 256) {
-    const int c = idx & 3, key = idx >> 2;
-    const int row = key / ncol, ci = key - row * ncol;
-    const int kr = r0 + row, kc = ci - 2;
-    f32x4q kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-    if (kr >= 0 && kr < p.n1 && kc >= 0 && kc < p.n2) {
-      const long long pix = base + kr * p.st1 + kc * p.st2;
-      kv = *reinterpret_cast<const f32x4q*>(p.K + pix * p.k_stride + p.k_choff + head * 16 + 4 * c);
-      vv = *reinterpret_cast<const f32x4q*>(p.V + pix * p.v_stride + p.v_choff + head * 16 + 4 * c);
-    }
-    const int kl = row * WA_KP + ci;
-    *reinterpret_cast<f32x4q*>(sK + kl * 16 + (((c + (kl >> 2)) & 3) << 2)) = kv;
+  // ---- this wave's queries first (their HBM latency runs under the staging): tile = wave, wave + 4, ... (at most 4 per wave at n2 <= 32) ----
+  const int ntile = 2 * p.ntc;
+  f32x4q qreg[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sVt[(4 * c + j) * WA_VD + kl] = vv[j];
+  for (int i = 0; i < 4; ++i) {
+    const int tile = wave + 4 * i;
+    qreg[i] = f32x4q{0.f, 0.f, 0.f, 0.f};
+    if (tile < ntile) {
+      const int al = tile / p.ntc, b = tile - al * p.ntc;
+      const int qr = strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
+      const bool qok = qr < p.n1 && qc < p.n2;
+      const long long qpix = base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
+      qreg[i] = *reinterpret_cast<const f32x4q*>(p.Q + qpix * p.q_stride + p.q_choff + head * 16 + 4 * g);
+    }
+  }
+  // ---- stage K and V^T of this head for the 12 key rows (item = (key, 16-B chunk c of its 64-B head slice); keys outside the image are zeros).  All of a
+  // thread's loads are issued before its first LDS store: as a plain loop every iteration is one serial memory round trip (7 per block, the whole kernel's time) ----
+  {
+    constexpr int NIT = (WA_ROWS * 36 * 4 + 255) / 256;       // 7: items per thread at the widest geometry
+    const int nitem = WA_ROWS * ncol * 4;
+    const unsigned magic = (65536u + ncol - 1) / ncol;        // key / ncol = (key * magic) >> 16 for key < 432 (ncol <= 36)
+    f32x4q kv[NIT], vv[NIT];
+    int kls[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 256 * it;
+      const int c = idx & 3, key = idx >> 2;
+      const int row = (int)(((unsigned)key * magic) >> 16), ci = key - row * ncol;
+      const int kr = r0 + row, kc = ci - 2;
+      kv[it] = f32x4q{0.f, 0.f, 0.f, 0.f}; vv[it] = kv[it];
+      kls[it] = idx < nitem ? row * WA_KP + ci : -1;
+      if (idx < nitem && kr >= 0 && kr < p.n1 && kc >= 0 && kc < p.n2) {
+        const long long pix = base + kr * p.st1 + kc * p.st2;
+        kv[it] = *reinterpret_cast<const f32x4q*>(p.K + pix * p.k_stride + p.k_choff + head * 16 + 4 * c);
+        vv[it] = *reinterpret_cast<const f32x4q*>(p.V + pix * p.v_stride + p.v_choff + head * 16 + 4 * c);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int kl = kls[it], c = tid & 3;                    // (256 is a multiple of 4: the chunk index does not depend on it)
+      if (kl >= 0) {
+        *reinterpret_cast<f32x4q*>(sK + kl * 16 + (((c + (kl >> 2)) & 3) << 2)) = kv[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sVt[(4 * c + j) * WA_VD + kl] = vv[it][j];
+      }
+    }
   }
   __syncthreads();
 
-  const int ntile = 2 * p.ntc;
-  for (int tile = wave; tile < ntile; tile += 4) {
+#pragma unroll
+  for (int ti = 0; ti < 4; ++ti) {
+    const int tile = wave + 4 * ti;
+    if (tile >= ntile) break;
     const int al = tile / p.ntc, b = tile - al * p.ntc;     // tile row inside the strip (0 / 1), tile column
     // this lane's query
     const int qr = strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
     const bool qok = qr < p.n1 && qc < p.n2;
     const long long qpix = base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
-    f32x4q qb = *reinterpret_cast<const f32x4q*>(p.Q + qpix * p.q_stride + p.q_choff + head * 16 + 4 * g);
-    qb *= p.scale;
+    const f32x4q qb = qreg[ti] * p.scale;
     // registers r of a key tile kt hold key (row 4 al + 2 kt + (g >> 1), column 4 b + 4 (g & 1) + r) of the staged block
     const int kc0 = 4 * b - 2 + 4 * (g & 1);               // token column of register 0
     f32x4q S[4];
