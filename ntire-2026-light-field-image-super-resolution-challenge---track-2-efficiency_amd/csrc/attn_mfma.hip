@@ -55,42 +55,62 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
   float* const sK = smem + h4 * HEAD_FLOATS;
   float* const sVt = sK + LR * 16;
 
-  // ---- stage K and V^T of this head (the head's two waves: 128 threads; item = (token, 16-B chunk c of its 64-B head slice)) ----
+  // ---- stage K and V^T of this head (the head's two waves: 128 threads; item = (token, 16-B chunk c of its 64-B head slice)).  All of a thread's loads are
+  // issued before its first LDS store (round 3: as a loop unrolled by two the five items of a thread were three serial memory round trips per block) ----
   {
     const int t128 = half * 64 + lane;
-#pragma unroll 2
-    for (int idx = t128; idx < LR * 4; idx += 128) {
+    constexpr int NIT = (LR * 4 + 127) / 128;
+    f32x4a kv[NIT], vv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t128 + 128 * it;
       const int tok = idx >> 2, c = idx & 3;
-      f32x4a kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-      if (tok < p.L) {
+      kv[it] = f32x4a{0.f, 0.f, 0.f, 0.f}; vv[it] = kv[it];
+      if (idx < LR * 4 && tok < p.L) {
         const int t2 = tok / n1, t1 = tok - t2 * n1;
         const long long pix = base + t1 * p.st1 + t2 * p.st2;
-        kv = *reinterpret_cast<const f32x4a*>(p.K + pix * p.k_stride + p.k_choff + head * 16 + 4 * c);
-        vv = *reinterpret_cast<const f32x4a*>(p.V + pix * p.v_stride + p.v_choff + head * 16 + 4 * c);
+        kv[it] = *reinterpret_cast<const f32x4a*>(p.K + pix * p.k_stride + p.k_choff + head * 16 + 4 * c);
+        vv[it] = *reinterpret_cast<const f32x4a*>(p.V + pix * p.v_stride + p.v_choff + head * 16 + 4 * c);
       }
-      *reinterpret_cast<f32x4a*>(sK + tok * 16 + (((c + (tok >> 2)) & 3) << 2)) = kv;
+    }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int d = 4 * c + j;
-        int col = tok + 4 * d;
-        col = col >= LR ? col - LR : col;
-        sVt[d * LR + col] = vv[j];
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t128 + 128 * it;
+      if (idx < LR * 4) {
+        const int tok = idx >> 2, c = idx & 3;
+        *reinterpret_cast<f32x4a*>(sK + tok * 16 + (((c + (tok >> 2)) & 3) << 2)) = kv[it];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int d = 4 * c + jj;
+          int col = tok + 4 * d;
+          col = col >= LR ? col - LR : col;
+          sVt[d * LR + col] = vv[it][jj];
+        }
       }
     }
   }
   __syncthreads();
 
   const int kmax = min(p.n2, p.clip2);
-  for (int qt = half; qt < NT; qt += 2) {
-    if (qt * 16 >= p.L) break;
+  // the wave's queries (every other tile of 16) are requested up front: inside the loop each tile's load was a serial memory round trip
+  f32x4a qpre[(NT + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < (NT + 1) / 2; ++i) {
+    const int qtok = (half + 2 * i) * 16 + l15;
+    const int qc = qtok < p.L ? qtok : p.L - 1;
+    const int t2q = qc / n1, t1q = qc - t2q * n1;
+    qpre[i] = *reinterpret_cast<const f32x4a*>(p.Q + (base + t1q * p.st1 + t2q * p.st2) * p.q_stride + p.q_choff + head * 16 + 4 * g);
+  }
+#pragma unroll
+  for (int qt = half, qi = 0; qi < (NT + 1) / 2; qt += 2, ++qi) {
+    if (qt >= NT || qt * 16 >= p.L) break;
     // ---- this lane's query, its band of valid keys and the (wave-uniform) range of key tiles of the whole query tile ----
     const int qtok = qt * 16 + l15;
     const bool qok = qtok < p.L;
     const int qc = qok ? qtok : p.L - 1;
     const int t2q = qc / n1, t1q = qc - t2q * n1;
     const long long qpix = base + t1q * p.st1 + t2q * p.st2;
-    f32x4a qb = *reinterpret_cast<const f32x4a*>(p.Q + qpix * p.q_stride + p.q_choff + head * 16 + 4 * g);
-    qb *= p.scale;
+    const f32x4a qb = qpre[qi] * p.scale;
     const int lo = max(0, t2q - p.l2) * n1, hi = min(kmax, t2q + p.r2) * n1;
     const int kbase = 4 * g - lo;
     const unsigned kwidth = (unsigned)(hi > lo ? hi - lo : 0);

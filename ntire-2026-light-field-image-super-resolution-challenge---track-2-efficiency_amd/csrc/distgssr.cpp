@@ -37,6 +37,9 @@ struct lfsr_distgssr {
   std::vector<LfsrPackDesc> d_gen, d_c3, d_epi, d_epib, uploaded;
   LfsrPackDesc* table_dev = nullptr;
   size_t table_cap = 0;
+  // backward: the weight gradient of a 3x3 layer runs on a side stream beside the layer's data gradient (both read the same dY); created on first use
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool profiling = false;
   struct Ev { int cls; hipEvent_t a, b; };
   bool profile_all = true;
@@ -108,6 +111,9 @@ void lfsr_distgssr_destroy(lfsr_distgssr* c) {
   for (auto& e : c->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto e : c->free_evs) (void)hipEventDestroy(e);
   if (c->table_dev) (void)hipFree(c->table_dev);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
 
@@ -499,15 +505,45 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   int rc;
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
   auto G = [&](const std::string& k) -> float* { return grads + c->slots.at(k).grad_off; };
+  // The weight gradient and the data gradient of a 3x3 layer read the same dY and are independent: the weight gradient goes to a side stream (fork: an event
+  // recorded on the caller's stream once dY exists) and the caller's stream joins it right behind the data gradient, before anything may overwrite dY, the
+  // saved activation or the partial slabs.  At B = 8 the persistent conv kernel leaves 224 of 256 CUs idle in its fourth tile round (800 tiles): the weight
+  // gradient's blocks fill them.  Every wgrad3 is followed by its dgrad3 below.  LFSR_BWD_OVERLAP=0: one stream (A/B runs).  Not under stream capture.
+  bool overlap = false;
+  {
+    const char* osel = getenv("LFSR_BWD_OVERLAP");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (!(osel && osel[0] == '0') && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+      if (!c->side) {
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+        if (c->side && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
+          (void)hipStreamDestroy(c->side); c->side = nullptr;
+        }
+      }
+      overlap = c->side != nullptr;
+    }
+  }
+  bool forked = false;
   // weight gradient of a 3x3 conv: dW[tap][n][k] = sum_m g[m][n] * xin[conv3 src(m,tap)][k]
   auto wgrad3 = [&](const std::string& key, const float* xin, const float* g, int g_stride) -> int {
-    int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.P[0], nimg, h, w, st);
-    if (r) return r;
-    return lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, st);
+    hipStream_t ws = st;
+    if (overlap) {
+      if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return LFSR_E_ARG;
+      ws = c->side; forked = true;
+    }
+    int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.P[0], nimg, h, w, ws);
+    if (!r) r = lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, ws);
+    if (overlap && hipEventRecord(c->ev_join, c->side) != hipSuccess) return LFSR_E_ARG;
+    return r;
   };
   auto dgrad3 = [&](const float* dy, int dy_stride, const std::string& key, float* dx, const float* r1, const float* r2_unused, const float* mk, int mk_stride) -> int {
     (void)r2_unused;
-    return lfsr_conv3x3_bwd_data(dy, dy_stride, 0, c->wT(key), dx, 64, 0, r1, 64, 0, mk, mk_stride, 0, L, nimg, h, w, st);
+    const int r = lfsr_conv3x3_bwd_data(dy, dy_stride, 0, c->wT(key), dx, 64, 0, r1, 64, 0, mk, mk_stride, 0, L, nimg, h, w, st);
+    if (forked) {                        // join: the caller's stream continues only after the side stream's weight gradient
+      forked = false;
+      if (hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) return LFSR_E_ARG;
+    }
+    return r;
   };
   auto pick = [&](const float* a, const float* b, const float* d) -> float* {
     for (int i = 0; i < 4; ++i)

@@ -30,6 +30,7 @@ struct WinAttnArgs {
   int ns1, ns2; long long bs0, bs1, bs2;
   int n1, n2; long long st1, st2;
   int kmax;        // min(n2, clip2): first invalid key column
+  unsigned nheads;
   int nstrip, ntc; // strips of 8 query rows per sequence; 4-column query tiles per row
   float scale;     // 1 / sqrt(16) * log2(e)
 };
@@ -40,8 +41,22 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
   float* const sVt = smem + WA_ROWS * WA_KP * 16;           // [16][484]: [d][row * 40 + col]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int head = blockIdx.y;
-  int t = blockIdx.x;
+  // Block order: the heads of one (sequence, strip) read the SAME token rows (a head's slice is 64 B of a 512-B / 1-KB row), so they must meet in one L2:
+  // consecutive workgroups go to consecutive XCDs, hence block id = (slot j, xcd), j = (strip-group, head): the nheads blocks of a strip run back to back on one XCD
+  // and each 128-B line comes from HBM once.  (With the heads as the slow grid dimension every line was fetched once per head: the kernel ran at the HBM limit of 2x its bytes.)
+  int head, t;
+  {
+    const unsigned nblk = gridDim.x / p.nheads;          // (sequence, strip) units
+    const unsigned id = blockIdx.x;
+    if ((nblk & 7u) == 0u) {
+      const unsigned xcd = id & 7u, j = id >> 3;
+      head = (int)(j % p.nheads);
+      t = (int)((j / p.nheads) * 8u + xcd);
+    } else {
+      head = (int)(id % p.nheads);
+      t = (int)(id / p.nheads);
+    }
+  }
   const int strip = t % p.nstrip; t /= p.nstrip;
   const int s2 = t % p.ns2; t /= p.ns2;
   const int s1 = t % p.ns1;
@@ -177,7 +192,8 @@ int lfsr_win_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
   p.nstrip = (n1 + 7) / 8; p.ntc = (n2 + 3) / 4;
   p.scale = (1.0f / sqrtf(16.0f)) * 1.44269504088896340736f;
   const long long nblk = (long long)ns0 * ns1 * ns2 * p.nstrip;
-  if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;
+  if (nblk <= 0 || nblk * nheads > 0x7fffffffLL) return LFSR_E_ARG;
+  p.nheads = (unsigned)nheads;
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
@@ -186,7 +202,7 @@ int lfsr_win_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(k_win_attn_mfma, dim3((unsigned)nblk, (unsigned)nheads), dim3(256), WA_SMEM, st, p);
+  hipLaunchKernelGGL(k_win_attn_mfma, dim3((unsigned)(nblk * nheads)), dim3(256), WA_SMEM, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
