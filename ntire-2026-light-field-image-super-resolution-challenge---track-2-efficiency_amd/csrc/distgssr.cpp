@@ -508,12 +508,14 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   // The weight gradient and the data gradient of a 3x3 layer read the same dY and are independent: the weight gradient goes to a side stream (fork: an event
   // recorded on the caller's stream once dY exists) and the caller's stream joins it right behind the data gradient, before anything may overwrite dY, the
   // saved activation or the partial slabs.  At B = 8 the persistent conv kernel leaves 224 of 256 CUs idle in its fourth tile round (800 tiles): the weight
-  // gradient's blocks fill them.  Every wgrad3 is followed by its dgrad3 below.  LFSR_BWD_OVERLAP=0: one stream (A/B runs).  Not under stream capture.
+  // gradient's blocks could fill them.  MEASURED NEGATIVE (round 3, two runs each in one call, profiles/r03_logs/c6_overlap.txt): 25.3 ms with the side stream against
+  // 24.5 ms on one stream -- both kernels are persistent one-block-per-CU grids (159 KB / 115 KB of LDS: never co-resident on a CU), so interleaving their blocks only
+  // lengthens both.  Kept as an option: LFSR_BWD_OVERLAP=1.  Every wgrad3 is followed by its dgrad3 below.  Not under stream capture.
   bool overlap = false;
   {
     const char* osel = getenv("LFSR_BWD_OVERLAP");
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (!(osel && osel[0] == '0') && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+    if (osel && osel[0] == '1' && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
       if (!c->side) {
         if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
         if (c->side && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {

@@ -7,12 +7,12 @@
 // Formulation.  In VCL the 1x25 conv is a 5-tap 1-D conv along the EPI line over 5 views x 64 channels.  With N = SOURCE positions instead of output
 // positions the five taps share their B operands:  Z_dx[n][s] = sum_{v', c} W[5 dx + v'][n][c] X[v'][s][c]  for the 32 sources of a line (the two
 // padding positions on either side are zero and need no columns), then  t[x][n] = sum_dx Z_dx[n][x + dx - 2]  -- one shifted add of the five
-// accumulator tiles through a wave-private LDS tile.  So every input value is loaded ONCE (straight from global memory in B-operand order: lane =
+// accumulator tiles; the position index is the lane index within a row of 16, so the shift is a DPP row shift (+ the wrap from the neighbouring tile): no LDS.  So every input value is loaded ONCE (straight from global memory in B-operand order: lane =
 // source position, eight consecutive channels per k-group), split ONCE (5.5 VALU per element, in the shadow of the MFMAs) and feeds 5 taps x 32 outputs.
 // One wave = one EPI line = 80 accumulator registers; a persistent 512-thread block = 8 lines per group.  The weights arrive pre-split from the pack
-// (lfsr_pack_epi_b3) and are staged per (view, K step) in LDS, double-buffered behind ONE barrier per stage (30 KB per stage, straight copy);
-// stage 2 (1x1 32 -> 160) runs the same way from the LDS-resident planes of its weights, and its result goes out as 16-B stores per lane
-// (chunk = destination view = PixelShuffle1D).
+// (lfsr_pack_epi_b3) and are staged per VIEW in LDS (two K steps, 60 KB), double-buffered behind ONE barrier per view (straight copy, fetched half by half);
+// stage 2 (1x1 32 -> 160) runs the same way from the LDS-resident planes of its weights -- its B operand is the lane's own t registers as they stand, because
+// the pack stores W2's columns in the order a lane holds them -- and its result goes out as 16-B stores per lane (chunk = destination view = PixelShuffle1D).
 #include <stdlib.h>
 
 #include "lfsr_internal.h"
@@ -27,8 +27,7 @@ constexpr int EB_STAGE_SLOTS = 5 * 3 * 4 * 32;              // 16-B slots of one
 constexpr int EB_STAGE_BYTES = EB_STAGE_SLOTS * 16;         // 30720
 constexpr int EB_W2_SLOTS = 3 * 4 * 160;                    // [plane][k-group][n']
 constexpr int EB_W2_BYTES = EB_W2_SLOTS * 16;               // 30720
-constexpr int EB_TROW = 36;                                 // floats per row of a wave's exchange tile (144 B: 16 rows cover the 16 slots of a bank row once)
-constexpr int EB_SMEM = 2 * EB_STAGE_BYTES + EB_W2_BYTES + EB_LINES * 32 * EB_TROW * 4;     // 129024
+constexpr int EB_SMEM = 4 * EB_STAGE_BYTES + EB_W2_BYTES;   // two views of stage-1 planes (two K steps each) + the stage-2 planes: 153600
 
 struct EpiB3Args {
   const float* X; int x_stride; int x_choff; int x_bytes;
@@ -75,11 +74,30 @@ __device__ __forceinline__ void eb_six2(f32x4e& c0, f32x4e& c1, const u32x4e a0,
   eb_mfma(c0, a0, x00); eb_mfma(c1, a0, x10);
 }
 
+// lane i of a row of 16 reads lane i + N (row_shl) / i - N (row_shr) of the same row; lanes that would read outside the row get 0
+template <int CTRL>
+__device__ __forceinline__ float eb_dpp0(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// z[x + D] for the two position tiles of a line (x = 16 nt + l15; sources outside [0, 32) contribute nothing): a shift inside the tile plus the lanes that wrap
+// in from the neighbouring tile
+template <int D>
+__device__ __forceinline__ void eb_shift_add(f32x4e (&t)[2], const f32x4e (&z)[2]) {
+  constexpr int SAME = D > 0 ? 0x100 + D : 0x110 - D;                 // row_shl:D / row_shr:-D
+  constexpr int WRAP = D > 0 ? 0x110 + (16 - D) : 0x100 + (16 + D);   // row_shr:(16 - D) / row_shl:(16 + D)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    t[0][r] += eb_dpp0<SAME>(z[0][r]);
+    t[1][r] += eb_dpp0<SAME>(z[1][r]);
+    if (D > 0) t[0][r] += eb_dpp0<WRAP>(z[1][r]);                     // positions 16 - D .. 15 of tile 0 read positions 0 .. D - 1 of tile 1
+    else t[1][r] += eb_dpp0<WRAP>(z[0][r]);                           // positions 0 .. -D - 1 of tile 1 read positions 16 + D .. 15 of tile 0
+  }
+}
+
 __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char* const sW = smem_raw;                                   // [2][EB_STAGE_BYTES]
-  unsigned char* const sW2 = smem_raw + 2 * EB_STAGE_BYTES;             // [EB_W2_BYTES]
-  float* const sT = reinterpret_cast<float*>(smem_raw + 2 * EB_STAGE_BYTES + EB_W2_BYTES);   // [8 waves][32][EB_TROW]
+  unsigned char* const sW = smem_raw;                                   // [2 views][2 K steps][EB_STAGE_BYTES]
+  unsigned char* const sW2 = smem_raw + 4 * EB_STAGE_BYTES;             // [EB_W2_BYTES]
   constexpr int A = 5;
   constexpr int EOOB = (int)0x80000000u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,11 +142,11 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
     return L;
   };
 
-  // raw input, two stages deep ([source tile nt][lo / hi four floats]) and its planes, double-buffered: stage j's MFMAs read planes P(j & 1) while the raw values of
-  // stage j + 1 are split into the other set IN THEIR SHADOW (two slices pinned between MFMA groups) and the loads of stage j + 2 fly
+  // raw input, two steps deep ([source tile nt][lo / hi four floats]) and its planes, double-buffered: step j's MFMAs read planes P(j & 1) while the raw values of
+  // step j + 1 are split into the other set IN THEIR SHADOW (a pair of values pinned behind each MFMA group) and the loads of step j + 2 fly
   f32x4e rawA[2][2], rawB[2][2];
   u32x4e pA0[2], pA1[2], pA2[2], pB0[2], pB1[2], pB2[2];
-  auto load_x = [&](const Line& L, int j, f32x4e (&xr)[2][2]) {   // stage j = 2 v' + ks of the line
+  auto load_x = [&](const Line& L, int j, f32x4e (&xr)[2][2]) {   // step j = 2 v' + ks of the line
     const int vv = j >> 1, ks = j & 1;
     const int soff = (vv * L.vstride * p.x_stride + 32 * ks) * 4;
 #pragma unroll
@@ -139,17 +157,19 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
       xr[nt][1] = __builtin_bit_cast(f32x4e, __builtin_amdgcn_raw_buffer_load_b128(rsX, off == EOOB ? EOOB : off + 16, soff, 0));
     }
   };
-  uint4 wr[4];                          // weight slots of the NEXT stage (3.75 per thread)
-  auto load_w = [&](int j) {
-    const uint4* src = p.W1p + j * EB_STAGE_SLOTS;
+  // weights: one LDS buffer per VIEW (both K steps, 60 KB), double-buffered: ONE barrier per view.  The next view's image is fetched half by half (its K step ks during
+  // this view's step ks) and stored into the other buffer at the end of the step -- that buffer was read last during the previous view, whose barrier every wave has passed
+  uint4 wr[4];
+  auto load_w = [&](int half_idx) {      // half_idx = 2 view + ks
+    const uint4* src = p.W1p + half_idx * EB_STAGE_SLOTS;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 512 * i;
       wr[i] = idx < EB_STAGE_SLOTS ? src[idx] : make_uint4(0u, 0u, 0u, 0u);
     }
   };
-  auto store_w = [&](int buf) {
-    uint4* dst = reinterpret_cast<uint4*>(sW + buf * EB_STAGE_BYTES);
+  auto store_w = [&](int buf, int ks) {
+    uint4* dst = reinterpret_cast<uint4*>(sW + (buf * 2 + ks) * EB_STAGE_BYTES);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 512 * i;
@@ -170,13 +190,15 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const int idx = tid + 512 * i; if (idx < EB_W2_SLOTS) reinterpret_cast<uint4*>(sW2)[idx] = w2r[i]; }
   }
-  store_w(0);
+  store_w(0, 0);
+  load_w(1);
+  store_w(0, 1);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) eb_split8(rawA[nt][0], rawA[nt][1], pA0[nt], pA1[nt], pA2[nt]);
   __syncthreads();
-  int cur = 0;
+  int cur = 0;                                          // buffer of the current view
   const int aoff = (g * 32 + l15) * 16;                 // this lane's A-operand slot inside a (dx, plane) block: k-group g, weight row l15 (+ 16 mt)
-  float* const sTw = sT + wave * 32 * EB_TROW;
+  const unsigned char* const w2b = sW2 + (g * 160 + l15) * 16;
 
   for (;;) {
     const int ngrp = grp + nb;
@@ -190,14 +212,15 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) asm volatile("s_nop 1" : "+v"(acc[dx][0][0]), "+v"(acc[dx][0][1]), "+v"(acc[dx][1][0]), "+v"(acc[dx][1][1]));
 
-    // one stage: MFMAs of stage j on the planes (u0, u1, u2); raw values rs (stage j + 1) split into (d0, d1, d2); loads of stage j + 2 into rd
-    auto stage = [&](int j, u32x4e (&u0)[2], u32x4e (&u1)[2], u32x4e (&u2)[2], f32x4e (&rs)[2][2], u32x4e (&d0)[2], u32x4e (&d1)[2], u32x4e (&d2)[2],
-                     f32x4e (&rd)[2][2]) {
+    // one step: MFMAs of step j on the planes (u0, u1, u2); raw values rs (step j + 1) split into (d0, d1, d2); loads of step j + 2 into rd
+    auto step = [&](int j, u32x4e (&u0)[2], u32x4e (&u1)[2], u32x4e (&u2)[2], f32x4e (&rs)[2][2], u32x4e (&d0)[2], u32x4e (&d1)[2], u32x4e (&d2)[2],
+                    f32x4e (&rd)[2][2]) {
+      const int vv = j >> 1, ks = j & 1;
       if (j + 2 < 10) load_x(L, j + 2, rd);
       else load_x(Ln, j + 2 - 10, rd);
-      load_w(j + 1 < 10 ? j + 1 : 0);
+      load_w(2 * (vv + 1 < A ? vv + 1 : 0) + ks);
       asm volatile("s_nop 4" : "+v"(u0[0]), "+v"(u1[0]), "+v"(u2[0]), "+v"(u0[1]), "+v"(u1[1]), "+v"(u2[1]));
-      const unsigned char* wb = sW + cur * EB_STAGE_BYTES + aoff;
+      const unsigned char* wb = sW + (cur * 2 + ks) * EB_STAGE_BYTES + aoff;
       // A operands (the weights' planes of tap dx, row tile mt) one group ahead of their MFMAs
       u32x4e af[2][3];
       auto load_a = [&](int c, u32x4e (&a)[3]) {
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
         const int dx = c >> 1, mt = c & 1;
         if (c + 1 < 10) load_a(c + 1, af[(c + 1) & 1]);
         eb_six2(acc[dx][mt][0], acc[dx][mt][1], af[c & 1][0], af[c & 1][1], af[c & 1][2], u0[0], u1[0], u2[0], u0[1], u1[1], u2[1]);
-        // the next stage's split, one pair of values (11 VALU) behind each of the first eight MFMA groups: volatile asm statements keep their order, so "defining"
+        // the next step's split, one pair of values (11 VALU) behind each of the first eight MFMA groups: volatile asm statements keep their order, so "defining"
         // the inputs here and "using" the outputs below fences the slice between two groups -- in the MFMAs' shadow instead of in a burst of its own
         if (c < 8) {
           const int nt = c >> 2, k = c & 3;
@@ -224,45 +247,29 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
           asm volatile("" : "+v"(d0[nt]), "+v"(d1[nt]), "+v"(d2[nt]));
         }
       }
-      store_w(cur ^ 1);                 // (read last in the stage before this one: every wave has passed that stage's barrier)
-      __syncthreads();
-      cur ^= 1;
+      store_w(cur ^ 1, ks);
+      if (ks) { __syncthreads(); cur ^= 1; }
     };
 #pragma unroll 1
     for (int jj = 0; jj < 10; jj += 2) {
-      stage(jj, pA0, pA1, pA2, rawB, pB0, pB1, pB2, rawA);
-      stage(jj + 1, pB0, pB1, pB2, rawA, pA0, pA1, pA2, rawB);
+      step(jj, pA0, pA1, pA2, rawB, pB0, pB1, pB2, rawA);
+      step(jj + 1, pB0, pB1, pB2, rawA, pA0, pA1, pA2, rawB);
     }
 
-    // ---- t[x][n] = sum_dx Z_dx[n][x + dx - 2]: the centre tap as it stands, the others shifted through the wave's LDS tile ----
+    // ---- t[x][n] = sum_dx Z_dx[n][x + dx - 2]: the centre tap as it stands, the others shifted along the position index = the lane index within a row of 16:
+    //      DPP row shifts inside a tile plus the lanes that wrap in from the neighbouring tile (no LDS round trip) ----
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx)
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[dx][0][0]), "+v"(acc[dx][0][1]), "+v"(acc[dx][1][0]), "+v"(acc[dx][1][1]));
     f32x4e tv[2][2];                    // [mt][nt]: channels 16 mt + 4 g .. + 3 of position 16 nt + l15
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) { tv[mt][0] = acc[2][mt][0]; tv[mt][1] = acc[2][mt][1]; }
-#pragma unroll
-    for (int di = 0; di < 4; ++di) {
-      const int dx = di < 2 ? di : di + 1;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<f32x4e*>(sTw + (16 * nt + l15) * EB_TROW + 16 * mt + 4 * g) = acc[dx][mt][nt];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int r = 16 * nt + l15 + dx - 2;
-        const bool ok = r >= 0 && r < 32;
-        const int rc = ok ? r : 0;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          const f32x4e z = *reinterpret_cast<const f32x4e*>(sTw + rc * EB_TROW + 16 * mt + 4 * g);
-          tv[mt][nt] += ok ? z : f32x4e{0.f, 0.f, 0.f, 0.f};
-        }
-      }
+    for (int mt = 0; mt < 2; ++mt) {
+      tv[mt][0] = acc[2][mt][0]; tv[mt][1] = acc[2][mt][1];
+      eb_shift_add<-2>(tv[mt], acc[0][mt]);
+      eb_shift_add<-1>(tv[mt], acc[1][mt]);
+      eb_shift_add<1>(tv[mt], acc[3][mt]);
+      eb_shift_add<2>(tv[mt], acc[4][mt]);
     }
-    __builtin_amdgcn_wave_barrier();
     {
       float* tsave = L.vert ? p.TV : p.TH;
       const bool save = tsave && L.base >= 0;
@@ -273,49 +280,51 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float v = tv[mt][nt][r]; tv[mt][nt][r] = v >= 0.f ? v : v * p.slope; }
           const int pos = 16 * nt + l15;
-          *reinterpret_cast<f32x4e*>(sTw + pos * EB_TROW + 16 * mt + 4 * g) = tv[mt][nt];
           if (save && pos < L.len) *reinterpret_cast<f32x4e*>(tsave + (L.rowbase + (long long)pos * L.rowstep) * 32 + 16 * mt + 4 * g) = tv[mt][nt];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    // ---- stage 2: y[n'][x] = lrelu(sum_k W2[n'][k] t[x][k]), K = 32 = one K step; B operand = the t rows (lane: position, k-group g) ----
+    // ---- stage 2: y[n'][x] = lrelu(sum_k W2[n'][k] t[x][k]), K = 32 = one K step.  The lane (position, g) already HOLDS eight of its position's channels
+    //      (16 mt + 4 g + r): they are its B operand as they stand once the pack stores W2's columns in that order (k slot 8 g + 4 mt + r <-> channel 16 mt + 4 g + r) ----
     u32x4e t0[2], t1[2], t2[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const float* tp = sTw + (16 * nt + l15) * EB_TROW + 8 * g;
-      eb_split8(*reinterpret_cast<const f32x4e*>(tp), *reinterpret_cast<const f32x4e*>(tp + 4), t0[nt], t1[nt], t2[nt]);
-    }
+    for (int nt = 0; nt < 2; ++nt) eb_split8(tv[0][nt], tv[1][nt], t0[nt], t1[nt], t2[nt]);
     asm volatile("s_nop 4" : "+v"(t0[0]), "+v"(t1[0]), "+v"(t2[0]), "+v"(t0[1]), "+v"(t1[1]), "+v"(t2[1]));
-    const unsigned char* w2b = sW2 + (g * 160 + l15) * 16;
+    int yoff[2];                        // float offset of this lane's pixel (chunk 0) in Y, or -1
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int pos = 16 * nt + l15;
+      yoff[nt] = (L.base >= 0 && pos < L.len) ? (L.base + pos * L.pstride) * p.y_stride + L.choff + 4 * g : -1;
+    }
+    const int ychunk = L.vstride * p.y_stride;
+    u32x4e w2f[2][2][3];                // [parity of mp][h][plane]
+    auto load_w2 = [&](int mp, u32x4e (&a)[2][3]) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[h][pl] = *reinterpret_cast<const u32x4e*>(w2b + ((pl * 4) * 160 + 16 * (2 * mp + h)) * 16);
+    };
+    load_w2(0, w2f[0]);
 #pragma unroll
     for (int mp = 0; mp < 5; ++mp) {    // destination view = chunk mp: its 32 channels = weight-row tiles 2 mp, 2 mp + 1
+      if (mp + 1 < 5) load_w2(mp + 1, w2f[(mp + 1) & 1]);
       f32x4e o[2][2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) { o[h][0] = f32x4e{0.f, 0.f, 0.f, 0.f}; o[h][1] = o[h][0]; }
       asm volatile("s_nop 1" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[1][0]), "+v"(o[1][1]));
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int mt2 = 2 * mp + h;
-        const u32x4e a0 = *reinterpret_cast<const u32x4e*>(w2b + ((0 * 4) * 160 + 16 * mt2) * 16);
-        const u32x4e a1 = *reinterpret_cast<const u32x4e*>(w2b + ((1 * 4) * 160 + 16 * mt2) * 16);
-        const u32x4e a2 = *reinterpret_cast<const u32x4e*>(w2b + ((2 * 4) * 160 + 16 * mt2) * 16);
-        eb_six2(o[h][0], o[h][1], a0, a1, a2, t0[0], t1[0], t2[0], t0[1], t1[1], t2[1]);
-      }
+      for (int h = 0; h < 2; ++h)
+        eb_six2(o[h][0], o[h][1], w2f[mp & 1][h][0], w2f[mp & 1][h][1], w2f[mp & 1][h][2], t0[0], t1[0], t2[0], t0[1], t1[1], t2[1]);
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[1][0]), "+v"(o[1][1]));
-      if (L.base >= 0) {
-        const long long dview = (long long)L.base + (long long)mp * L.vstride;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int pos = 16 * nt + l15;
-          if (pos < L.len) {
-            float* yp = p.Y + (dview + (long long)pos * L.pstride) * p.y_stride + L.choff + 4 * g;
+      for (int nt = 0; nt < 2; ++nt) {
+        if (yoff[nt] >= 0) {
+          float* yp = p.Y + (long long)yoff[nt] + (long long)mp * ychunk;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              f32x4e v = o[h][nt];
+          for (int h = 0; h < 2; ++h) {
+            f32x4e v = o[h][nt];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * p.slope;
-              *reinterpret_cast<f32x4e*>(yp + 16 * h) = v;
-            }
+            for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * p.slope;
+            *reinterpret_cast<f32x4e*>(yp + 16 * h) = v;
           }
         }
       }
@@ -352,7 +361,10 @@ __device__ __forceinline__ void eb_pack_one(const float* __restrict__ src, uint4
   } else {
     if (i >= 4 * 160) return;                         // (g, n')
     const int n = i % 160, g = i / 160;
-    eb_planes8(src + n * 32 + 8 * g, p0, p1, p2);
+    float kk[8];                                      // k slot 8 g + j <-> hidden channel 16 (j >> 2) + 4 g + (j & 3): the order in which a lane of k_epi_b3 holds its t values
+#pragma unroll
+    for (int jx = 0; jx < 8; ++jx) kk[jx] = src[n * 32 + 16 * (jx >> 2) + 4 * g + (jx & 3)];
+    eb_planes8(kk, p0, p1, p2);
     uint4* o = dst + g * 160 + n;
     o[0] = p0; o[4 * 160] = p1; o[8 * 160] = p2;
   }
