@@ -17,6 +17,11 @@
 
 #include "lfsr_internal.h"
 
+#ifndef EB_ABL
+#define EB_ABL 0   // diagnostic timing builds (WRONG results; tools/build_abl.sh): 1 no split of the next step's input, 2 one A-operand read per step, 4 no weight staging,
+                   // 8 no input loads, 16 no tail (tap sum, stage 2, stores), 32 no barriers
+#endif
+
 namespace {
 
 typedef float f32x4e __attribute__((ext_vector_type(4)));
@@ -33,7 +38,7 @@ struct EpiB3Args {
   const float* X; int x_stride; int x_choff; int x_bytes;
   const uint4* W1p;     // [view 5][K step 2][EB_STAGE_SLOTS]  (lfsr_pack_epi_b3)
   const uint4* W2p;     // [EB_W2_SLOTS]
-  float* Y; int y_stride; int choffH; int choffV;
+  float* Y; int y_stride; int choffH; int choffV; int y_bytes;
   float* TH; float* TV;   // optional (lines * len, 32): post-LeakyReLU stage-1 activations saved for the backward
   int B, H, W;
   int tilesH, tilesV;     // groups per pass
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
   constexpr int EOOB = (int)0x80000000u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
+  const int phase = __builtin_amdgcn_readfirstlane(wave >> 2);     // the two waves of a SIMD: 0 / 1
   const int HW = p.H * p.W;
   const int ngroups = p.tilesH + p.tilesV;
   // consecutive workgroups go to consecutive XCDs: the blocks of one XCD walk a contiguous range of groups (both passes of an item share an L2)
@@ -109,6 +115,7 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
   const int vb = (nb & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
 
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, p.y_bytes, 0x00020000);
 
   // ---- group geometry (block-uniform) and this wave's line ----
   struct Line { int vert, base, len, vstride, pstride, choff; long long rowbase; int rowstep; };
@@ -216,9 +223,11 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
     auto step = [&](int j, u32x4e (&u0)[2], u32x4e (&u1)[2], u32x4e (&u2)[2], f32x4e (&rs)[2][2], u32x4e (&d0)[2], u32x4e (&d1)[2], u32x4e (&d2)[2],
                     f32x4e (&rd)[2][2]) {
       const int vv = j >> 1, ks = j & 1;
-      if (j + 2 < 10) load_x(L, j + 2, rd);
-      else load_x(Ln, j + 2 - 10, rd);
-      load_w(2 * (vv + 1 < A ? vv + 1 : 0) + ks);
+      if (!(EB_ABL & 8)) {
+        if (j + 2 < 10) load_x(L, j + 2, rd);
+        else load_x(Ln, j + 2 - 10, rd);
+      }
+      if (!(EB_ABL & 4)) load_w(2 * (vv + 1 < A ? vv + 1 : 0) + ks);
       asm volatile("s_nop 4" : "+v"(u0[0]), "+v"(u1[0]), "+v"(u2[0]), "+v"(u0[1]), "+v"(u1[1]), "+v"(u2[1]));
       const unsigned char* wb = sW + (cur * 2 + ks) * EB_STAGE_BYTES + aoff;
       // A operands (the weights' planes of tap dx, row tile mt) one group ahead of their MFMAs
@@ -232,23 +241,23 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
       for (int c = 0; c < 10; ++c) {
         const int dx = c >> 1, mt = c & 1;
-        if (c + 1 < 10) load_a(c + 1, af[(c + 1) & 1]);
-        eb_six2(acc[dx][mt][0], acc[dx][mt][1], af[c & 1][0], af[c & 1][1], af[c & 1][2], u0[0], u1[0], u2[0], u0[1], u1[1], u2[1]);
-        // the next step's split, one pair of values (11 VALU) behind each of the first eight MFMA groups: volatile asm statements keep their order, so "defining"
-        // the inputs here and "using" the outputs below fences the slice between two groups -- in the MFMAs' shadow instead of in a burst of its own
-        if (c < 8) {
-          const int nt = c >> 2, k = c & 3;
-          asm volatile("" : "+v"(rs[nt][k >> 1]));
-          const float a0f = rs[nt][k >> 1][(k & 1) * 2], a1f = rs[nt][k >> 1][(k & 1) * 2 + 1];
-          const float r0 = eb_residual(a0f), r1 = eb_residual(a1f), q0 = eb_residual(r0), q1 = eb_residual(r1);
-          d0[nt][k] = eb_hi_pair(__float_as_uint(a1f), __float_as_uint(a0f));
-          d1[nt][k] = eb_hi_pair(__float_as_uint(r1), __float_as_uint(r0));
-          d2[nt][k] = eb_hi_pair(__float_as_uint(q1), __float_as_uint(q0));
-          asm volatile("" : "+v"(d0[nt]), "+v"(d1[nt]), "+v"(d2[nt]));
+        if (c + 1 < 10 && !(EB_ABL & 2)) load_a(c + 1, af[(c + 1) & 1]);
+        constexpr int ABL2 = (EB_ABL & 2) ? 0 : 1;
+        eb_six2(acc[dx][mt][0], acc[dx][mt][1], af[(c & 1) * ABL2][0], af[(c & 1) * ABL2][1], af[(c & 1) * ABL2][2], u0[0], u1[0], u2[0], u0[1], u1[1], u2[1]);
+        // The next step's split (88 VALU) as ONE burst, at a point of the step that differs between the two waves of a SIMD (wave w and w + 4 share SIMD w & 3):
+        // beside a streaming MFMA wave a VALU instruction issues only every ~13-20 cycles, and interleaved with the wave's OWN MFMAs it holds those up as well
+        // (ablation, profiles/r03_logs/c8_epi_b3_ablations.log: the split sprinkled between the MFMA groups cost 52 of 234 us).  Phase-shifted, one wave's burst
+        // runs under the other wave's MFMA stream, which keeps the matrix pipe busy alone.  Volatile asm statements keep their order: "defining" the inputs and
+        // "using" the outputs pins the burst behind MFMA group `c`.
+        if (!(EB_ABL & 1) && c == (phase ? 5 : 0)) {
+          asm volatile("" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) eb_split8(rs[nt][0], rs[nt][1], d0[nt], d1[nt], d2[nt]);
+          asm volatile("" : "+v"(d0[0]), "+v"(d1[0]), "+v"(d2[0]), "+v"(d0[1]), "+v"(d1[1]), "+v"(d2[1]));
         }
       }
-      store_w(cur ^ 1, ks);
-      if (ks) { __syncthreads(); cur ^= 1; }
+      if (!(EB_ABL & 4)) store_w(cur ^ 1, ks);
+      if (ks) { if (!(EB_ABL & 32)) __syncthreads(); cur ^= 1; }
     };
 #pragma unroll 1
     for (int jj = 0; jj < 10; jj += 2) {
@@ -261,6 +270,15 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx)
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[dx][0][0]), "+v"(acc[dx][0][1]), "+v"(acc[dx][1][0]), "+v"(acc[dx][1][1]));
+    if (EB_ABL & 16) {                  // (keep the accumulators live: one store of their sum)
+      f32x4e sacc = acc[0][0][0];
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) sacc += acc[dx][0][1] + acc[dx][1][0] + acc[dx][1][1] + acc[dx][0][0];
+      if (L.base >= 0 && l15 < L.len) *reinterpret_cast<f32x4e*>(p.Y + (long long)(L.base + l15 * L.pstride) * p.y_stride + L.choff + 4 * g) = sacc;
+      if (!more) break;
+      grp = ngrp; L = Ln;
+      continue;
+    }
     f32x4e tv[2][2];                    // [mt][nt]: channels 16 mt + 4 g .. + 3 of position 16 nt + l15
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float v = tv[mt][nt][r]; tv[mt][nt][r] = v >= 0.f ? v : v * p.slope; }
+          for (int r = 0; r < 4; ++r) { const float v = tv[mt][nt][r]; tv[mt][nt][r] = fmaxf(v, v * p.slope); }     // LeakyReLU, 0 <= slope <= 1 (checked by the launcher)
           const int pos = 16 * nt + l15;
           if (save && pos < L.len) *reinterpret_cast<f32x4e*>(tsave + (L.rowbase + (long long)pos * L.rowstep) * 32 + 16 * mt + 4 * g) = tv[mt][nt];
         }
@@ -289,13 +307,13 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) eb_split8(tv[0][nt], tv[1][nt], t0[nt], t1[nt], t2[nt]);
     asm volatile("s_nop 4" : "+v"(t0[0]), "+v"(t1[0]), "+v"(t2[0]), "+v"(t0[1]), "+v"(t1[1]), "+v"(t2[1]));
-    int yoff[2];                        // float offset of this lane's pixel (chunk 0) in Y, or -1
+    int yoff[2];                        // byte offset of this lane's pixel (chunk 0) in Y; out of range for an absent pixel (the store is dropped)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int pos = 16 * nt + l15;
-      yoff[nt] = (L.base >= 0 && pos < L.len) ? (L.base + pos * L.pstride) * p.y_stride + L.choff + 4 * g : -1;
+      yoff[nt] = (L.base >= 0 && pos < L.len) ? ((L.base + pos * L.pstride) * p.y_stride + L.choff + 4 * g) * 4 : EOOB;
     }
-    const int ychunk = L.vstride * p.y_stride;
+    const int ychunk = L.vstride * p.y_stride * 4;      // bytes between destination views (wave-uniform)
     u32x4e w2f[2][2][3];                // [parity of mp][h][plane]
     auto load_w2 = [&](int mp, u32x4e (&a)[2][3]) {
 #pragma unroll
@@ -316,18 +334,14 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
         eb_six2(o[h][0], o[h][1], w2f[mp & 1][h][0], w2f[mp & 1][h][1], w2f[mp & 1][h][2], t0[0], t1[0], t2[0], t0[1], t1[1], t2[1]);
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(o[0][0]), "+v"(o[0][1]), "+v"(o[1][0]), "+v"(o[1][1]));
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        if (yoff[nt] >= 0) {
-          float* yp = p.Y + (long long)yoff[nt] + (long long)mp * ychunk;
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            f32x4e v = o[h][nt];
+        for (int h = 0; h < 2; ++h) {
+          f32x4e v = o[h][nt];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] >= 0.f ? v[r] : v[r] * p.slope;
-            *reinterpret_cast<f32x4e*>(yp + 16 * h) = v;
-          }
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], v[r] * p.slope);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, v), rsY, yoff[nt], __builtin_amdgcn_readfirstlane(mp * ychunk + 64 * h), 0);
         }
-      }
     }
     if (!more) break;
     grp = ngrp;
@@ -402,7 +416,8 @@ int lfsr_epi_b3_launch(const float* x, int x_stride, int x_choff, const float* w
   if (A != 5 || h > 32 || w > 32 || h <= 0 || w <= 0 || B <= 0) return LFSR_E_ARG;
   if ((x_stride | x_choff | y_stride | choffH | choffV) & 3) return LFSR_E_ARG;
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w1_planes | (uintptr_t)w2_planes | (uintptr_t)t_h | (uintptr_t)t_v) & 15) return LFSR_E_ARG;
-  if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x
+  if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31) || (long long)B * A * A * h * w * y_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets
+  if (!(slope >= 0.f && slope <= 1.f)) return LFSR_E_ARG;      // LeakyReLU as max(v, slope v)
   static std::atomic<bool> attr_set[64];
   static std::atomic<int> cus[64];
   int dev = 0;
@@ -418,6 +433,7 @@ int lfsr_epi_b3_launch(const float* x, int x_stride, int x_choff, const float* w
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.x_bytes = (int)((long long)B * A * A * h * w * x_stride * 4);
   p.W1p = reinterpret_cast<const uint4*>(w1_planes); p.W2p = reinterpret_cast<const uint4*>(w2_planes);
   p.Y = y; p.y_stride = y_stride; p.choffH = choffH; p.choffV = choffV; p.TH = t_h; p.TV = t_v;
+  p.y_bytes = (int)((long long)B * A * A * h * w * y_stride * 4);
   p.B = B; p.H = h; p.W = w; p.slope = slope;
   p.tilesH = (which & 1) ? (B * A * h + EB_LINES - 1) / EB_LINES : 0;
   p.tilesV = (which & 2) ? (B * A * w + EB_LINES - 1) / EB_LINES : 0;

@@ -31,6 +31,8 @@ struct WinAttnArgs {
   int n1, n2; long long st1, st2;
   int kmax;        // min(n2, clip2): first invalid key column
   unsigned nheads;
+  long long nunits;  // sequences x strips x heads
+  int remap;         // 1: the XCD-aware unit order (needs (sequences x strips) and the grid to be multiples of 8)
   int nstrip, ntc; // strips of 8 query rows per sequence; 4-column query tiles per row
   float scale;     // 1 / sqrt(16) * log2(e)
 };
@@ -41,53 +43,40 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
   float* const sVt = smem + WA_ROWS * WA_KP * 16;           // [16][484]: [d][row * 40 + col]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  // Block order: the heads of one (sequence, strip) read the SAME token rows (a head's slice is 64 B of a 512-B / 1-KB row), so they must meet in one L2:
-  // consecutive workgroups go to consecutive XCDs, hence block id = (slot j, xcd), j = (strip-group, head): the nheads blocks of a strip run back to back on one XCD
-  // and each 128-B line comes from HBM once.  (With the heads as the slow grid dimension every line was fetched once per head: the kernel ran at the HBM limit of 2x its bytes.)
-  int head, t;
-  {
-    const unsigned nblk = gridDim.x / p.nheads;          // (sequence, strip) units
-    const unsigned id = blockIdx.x;
-    if ((nblk & 7u) == 0u) {
-      const unsigned xcd = id & 7u, j = id >> 3;
-      head = (int)(j % p.nheads);
-      t = (int)((j / p.nheads) * 8u + xcd);
-    } else {
-      head = (int)(id % p.nheads);
-      t = (int)(id / p.nheads);
-    }
-  }
-  const int strip = t % p.nstrip; t /= p.nstrip;
-  const int s2 = t % p.ns2; t /= p.ns2;
-  const int s1 = t % p.ns1;
-  const int s0 = t / p.ns1;
-  const long long base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
-  const int r0 = strip * 8 - 2;                             // token row of staged key row 0
   const int ncol = 4 * p.ntc + 4;                           // staged key columns: token columns -2 .. 4 ntc + 1
-
-  // ---- this wave's queries first (their HBM latency runs under the staging): tile = wave, wave + 4, ... (at most 4 per wave at n2 <= 32) ----
   const int ntile = 2 * p.ntc;
-  f32x4q qreg[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int tile = wave + 4 * i;
-    qreg[i] = f32x4q{0.f, 0.f, 0.f, 0.f};
-    if (tile < ntile) {
-      const int al = tile / p.ntc, b = tile - al * p.ntc;
-      const int qr = strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
-      const bool qok = qr < p.n1 && qc < p.n2;
-      const long long qpix = base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
-      qreg[i] = *reinterpret_cast<const f32x4q*>(p.Q + qpix * p.q_stride + p.q_choff + head * 16 + 4 * g);
+  const int nitem = WA_ROWS * ncol * 4;
+  const unsigned magic = (65536u + ncol - 1) / ncol;        // key / ncol = (key * magic) >> 16 for key < 432 (ncol <= 36)
+  constexpr int NIT = (WA_ROWS * 36 * 4 + 255) / 256;       // 7: staging items per thread at the widest geometry
+
+  // Persistent blocks over units (sequence, strip, head).  Unit order: the heads of one (sequence, strip) read the SAME token rows (a head's slice is 64 B of a
+  // 512-B / 1-KB row), so they must meet in one L2: consecutive workgroups go to consecutive XCDs, hence unit id = (slot j, xcd), j = (strip-group, head) -- the
+  // nheads units of a strip run at the same time on one XCD and each 128-B line comes from HBM once (with the heads as the slow dimension every line was fetched
+  // once per head).  A block's units are gridDim.x apart (a multiple of 8 whenever the remap applies), so it keeps its XCD.
+  struct Unit { int head, strip; long long base; };
+  auto unit_of = [&](long long u) -> Unit {
+    Unit U;
+    long long t;
+    if (p.remap) {
+      const long long xcd = u & 7, jx = u >> 3;
+      U.head = (int)(jx % p.nheads);
+      t = (jx / p.nheads) * 8 + xcd;
+    } else {
+      U.head = (int)(u % p.nheads);
+      t = u / p.nheads;
     }
-  }
-  // ---- stage K and V^T of this head for the 12 key rows (item = (key, 16-B chunk c of its 64-B head slice); keys outside the image are zeros).  All of a
-  // thread's loads are issued before its first LDS store: as a plain loop every iteration is one serial memory round trip (7 per block, the whole kernel's time) ----
-  {
-    constexpr int NIT = (WA_ROWS * 36 * 4 + 255) / 256;       // 7: items per thread at the widest geometry
-    const int nitem = WA_ROWS * ncol * 4;
-    const unsigned magic = (65536u + ncol - 1) / ncol;        // key / ncol = (key * magic) >> 16 for key < 432 (ncol <= 36)
-    f32x4q kv[NIT], vv[NIT];
-    int kls[NIT];
+    U.strip = (int)(t % p.nstrip); t /= p.nstrip;
+    const int s2 = (int)(t % p.ns2); t /= p.ns2;
+    const int s1 = (int)(t % p.ns1);
+    const long long s0 = t / p.ns1;
+    U.base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
+    return U;
+  };
+  // staging of a unit's 12 key rows, in two halves: every load of a thread is issued before its first LDS store, and the NEXT unit's loads fly under this unit's MFMAs
+  f32x4q kv[NIT], vv[NIT];
+  int kls[NIT];
+  auto fetch = [&](const Unit& U, bool valid) {
+    const int r0 = U.strip * 8 - 2;                         // token row of staged key row 0
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int idx = tid + 256 * it;
@@ -96,81 +85,121 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
       const int kr = r0 + row, kc = ci - 2;
       kv[it] = f32x4q{0.f, 0.f, 0.f, 0.f}; vv[it] = kv[it];
       kls[it] = idx < nitem ? row * WA_KP + ci : -1;
-      if (idx < nitem && kr >= 0 && kr < p.n1 && kc >= 0 && kc < p.n2) {
-        const long long pix = base + kr * p.st1 + kc * p.st2;
-        kv[it] = *reinterpret_cast<const f32x4q*>(p.K + pix * p.k_stride + p.k_choff + head * 16 + 4 * c);
-        vv[it] = *reinterpret_cast<const f32x4q*>(p.V + pix * p.v_stride + p.v_choff + head * 16 + 4 * c);
+      if (valid && idx < nitem && kr >= 0 && kr < p.n1 && kc >= 0 && kc < p.n2) {
+        const long long pix = U.base + kr * p.st1 + kc * p.st2;
+        kv[it] = *reinterpret_cast<const f32x4q*>(p.K + pix * p.k_stride + p.k_choff + U.head * 16 + 4 * c);
+        vv[it] = *reinterpret_cast<const f32x4q*>(p.V + pix * p.v_stride + p.v_choff + U.head * 16 + 4 * c);
       }
     }
+  };
+  auto stash = [&]() {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int kl = kls[it], c = tid & 3;                    // (256 is a multiple of 4: the chunk index does not depend on it)
+      const int kl = kls[it], c = tid & 3;                  // (256 is a multiple of 4: the chunk index does not depend on it)
       if (kl >= 0) {
         *reinterpret_cast<f32x4q*>(sK + kl * 16 + (((c + (kl >> 2)) & 3) << 2)) = kv[it];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sVt[(4 * c + j) * WA_VD + kl] = vv[it][j];
+        for (int jj = 0; jj < 4; ++jj) sVt[(4 * c + jj) * WA_VD + kl] = vv[it][jj];
       }
     }
-  }
-  __syncthreads();
+  };
+  f32x4q qreg[4];
+  auto fetch_q = [&](const Unit& U, bool valid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tile = wave + 4 * i;
+      qreg[i] = f32x4q{0.f, 0.f, 0.f, 0.f};
+      if (valid && tile < ntile) {
+        const int al = tile / p.ntc, b = tile - al * p.ntc;
+        const int qr = U.strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
+        const bool qok = qr < p.n1 && qc < p.n2;
+        const long long qpix = U.base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
+        qreg[i] = *reinterpret_cast<const f32x4q*>(p.Q + qpix * p.q_stride + p.q_choff + U.head * 16 + 4 * g);
+      }
+    }
+  };
 
+  long long u = blockIdx.x;
+  if (u >= p.nunits) return;                                // (block-uniform)
+  Unit U = unit_of(u);
+  fetch_q(U, true);
+  fetch(U, true);
+  stash();
+  __syncthreads();
+  for (;;) {
+    const long long un = u + gridDim.x;
+    const bool more = un < p.nunits;                        // (block-uniform)
+    const Unit Un = unit_of(more ? un : u);
+    f32x4q qcur[4];
 #pragma unroll
-  for (int ti = 0; ti < 4; ++ti) {
-    const int tile = wave + 4 * ti;
-    if (tile >= ntile) break;
-    const int al = tile / p.ntc, b = tile - al * p.ntc;     // tile row inside the strip (0 / 1), tile column
-    // this lane's query
-    const int qr = strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
-    const bool qok = qr < p.n1 && qc < p.n2;
-    const long long qpix = base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
-    const f32x4q qb = qreg[ti] * p.scale;
-    // registers r of a key tile kt hold key (row 4 al + 2 kt + (g >> 1), column 4 b + 4 (g & 1) + r) of the staged block
-    const int kc0 = 4 * b - 2 + 4 * (g & 1);               // token column of register 0
-    f32x4q S[4];
-    float m = -INFINITY;
+    for (int i = 0; i < 4; ++i) qcur[i] = qreg[i];
+    fetch(Un, more);                                        // the next unit's keys and queries: in flight during this unit's tiles
+    fetch_q(Un, more);
+    const int r0 = U.strip * 8 - 2;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int krow = 4 * al + 2 * kt + (l15 >> 3);
-      const int kl = krow * WA_KP + 4 * b + (l15 & 7);
-      const f32x4q ka = *reinterpret_cast<const f32x4q*>(sK + kl * 16 + (((g + (kl >> 2)) & 3) << 2));
-      f32x4q acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qb.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qb.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qb.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qb.w, acc, 0, 0, 0);
-      const int kr = r0 + 4 * al + 2 * kt + (g >> 1);       // token row of this lane group's keys
-      const bool rok = (unsigned)kr < (unsigned)p.n1 && (unsigned)(kr - qr + 2) < 5u;
+    for (int ti = 0; ti < 4; ++ti) {
+      const int tile = wave + 4 * ti;
+      if (tile >= ntile) break;
+      const int al = tile / p.ntc, b = tile - al * p.ntc;   // tile row inside the strip (0 / 1), tile column
+      // this lane's query
+      const int qr = U.strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
+      const bool qok = qr < p.n1 && qc < p.n2;
+      const long long qpix = U.base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
+      const f32x4q qb = qcur[ti] * p.scale;
+      // registers r of a key tile kt hold key (row 4 al + 2 kt + (g >> 1), column 4 b + 4 (g & 1) + r) of the staged block
+      const int kc0 = 4 * b - 2 + 4 * (g & 1);             // token column of register 0
+      f32x4q S[4];
+      float m = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kc = kc0 + r;
-        const bool ok = rok && (unsigned)kc < (unsigned)p.kmax && (unsigned)(kc - qc + 2) < 5u;
-        const float s = ok ? acc[r] : -INFINITY;
-        S[kt][r] = s;
-        m = fmaxf(m, s);
+      for (int kt = 0; kt < 4; ++kt) {
+        const int krow = 4 * al + 2 * kt + (l15 >> 3);
+        const int kl = krow * WA_KP + 4 * b + (l15 & 7);
+        const f32x4q ka = *reinterpret_cast<const f32x4q*>(sK + kl * 16 + (((g + (kl >> 2)) & 3) << 2));
+        f32x4q acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qb.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qb.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qb.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qb.w, acc, 0, 0, 0);
+        const int kr = r0 + 4 * al + 2 * kt + (g >> 1);     // token row of this lane group's keys
+        const bool rok = (unsigned)kr < (unsigned)p.n1 && (unsigned)(kr - qr + 2) < 5u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kc = kc0 + r;
+          const bool ok = rok && (unsigned)kc < (unsigned)p.kmax && (unsigned)(kc - qc + 2) < 5u;
+          const float sv = ok ? acc[r] : -INFINITY;
+          S[kt][r] = sv;
+          m = fmaxf(m, sv);
+        }
       }
-    }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float den = 0.f;
-    f32x4q o = {0.f, 0.f, 0.f, 0.f};
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float den = 0.f;
+      f32x4q o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      f32x4q pw;
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4q pw;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pw[r] = __builtin_amdgcn_exp2f(S[kt][r] - m);       // base-2 softmax (q carries log2 e); exp2(-inf) = 0 on masked keys; an empty window gives NaN like softmax over an all -inf row
-        den += pw[r];
+        for (int r = 0; r < 4; ++r) {
+          pw[r] = __builtin_amdgcn_exp2f(S[kt][r] - m);     // base-2 softmax (q carries log2 e); exp2(-inf) = 0 on masked keys; an empty window gives NaN like softmax over an all -inf row
+          den += pw[r];
+        }
+        const f32x4q va = *reinterpret_cast<const f32x4q*>(sVt + l15 * WA_VD + (4 * al + 2 * kt + (g >> 1)) * WA_KP + 4 * b + 4 * (g & 1));
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, pw.x, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, pw.y, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, pw.z, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, pw.w, o, 0, 0, 0);
       }
-      const f32x4q va = *reinterpret_cast<const f32x4q*>(sVt + l15 * WA_VD + (4 * al + 2 * kt + (g >> 1)) * WA_KP + 4 * b + 4 * (g & 1));
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, pw.x, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, pw.y, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, pw.z, o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, pw.w, o, 0, 0, 0);
+      den += __shfl_xor(den, 16);
+      den += __shfl_xor(den, 32);
+      const float inv = 1.0f / den;
+      if (qok) *reinterpret_cast<f32x4q*>(p.O + qpix * p.o_stride + p.o_choff + U.head * 16 + 4 * g) = o * inv;
     }
-    den += __shfl_xor(den, 16);
-    den += __shfl_xor(den, 32);
-    const float inv = 1.0f / den;
-    if (qok) *reinterpret_cast<f32x4q*>(p.O + qpix * p.o_stride + p.o_choff + head * 16 + 4 * g) = o * inv;
+    if (!more) break;
+    __syncthreads();                                        // every wave is done with this unit's keys
+    stash();
+    __syncthreads();
+    u = un;
+    U = Un;
   }
 }
 
@@ -194,15 +223,22 @@ int lfsr_win_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
   const long long nblk = (long long)ns0 * ns1 * ns2 * p.nstrip;
   if (nblk <= 0 || nblk * nheads > 0x7fffffffLL) return LFSR_E_ARG;
   p.nheads = (unsigned)nheads;
+  p.nunits = nblk * nheads;
   static std::atomic<bool> attr_set[64];
+  static std::atomic<int> cus[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_win_attn_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, WA_SMEM);
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(k_win_attn_mfma, dim3((unsigned)(nblk * nheads)), dim3(256), WA_SMEM, st, p);
+  long long grid = 2LL * cus[dev];                          // two 60-KB blocks per CU
+  if (grid > p.nunits) grid = p.nunits;
+  p.remap = (nblk % 8 == 0 && grid % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL(k_win_attn_mfma, dim3((unsigned)grid), dim3(256), WA_SMEM, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
