@@ -17,6 +17,9 @@
 
 #include "lfsr_internal.h"
 
+#ifndef EB_VAR
+#define EB_VAR 0   // bisecting builds (correct results): 1 select-form LeakyReLU, 2 pointer stores, 4 both waves of a SIMD split at the same point
+#endif
 #ifndef EB_ABL
 #define EB_ABL 0   // diagnostic timing builds (WRONG results; tools/build_abl.sh): 1 no split of the next step's input, 2 one A-operand read per step, 4 no weight staging,
                    // 8 no input loads, 16 no tail (tap sum, stage 2, stores), 32 no barriers
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
         // (ablation, profiles/r03_logs/c8_epi_b3_ablations.log: the split sprinkled between the MFMA groups cost 52 of 234 us).  Phase-shifted, one wave's burst
         // runs under the other wave's MFMA stream, which keeps the matrix pipe busy alone.  Volatile asm statements keep their order: "defining" the inputs and
         // "using" the outputs pins the burst behind MFMA group `c`.
-        if (!(EB_ABL & 1) && c == (phase ? 5 : 0)) {
+        if (!(EB_ABL & 1) && c == ((phase && !(EB_VAR & 4)) ? 5 : 0)) {
           asm volatile("" : "+v"(rs[0][0]), "+v"(rs[0][1]), "+v"(rs[1][0]), "+v"(rs[1][1]));
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) eb_split8(rs[nt][0], rs[nt][1], d0[nt], d1[nt], d2[nt]);
@@ -296,10 +299,11 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float v = tv[mt][nt][r]; tv[mt][nt][r] = fmaxf(v, v * p.slope); }     // LeakyReLU, 0 <= slope <= 1 (checked by the launcher)
+          for (int r = 0; r < 4; ++r) { const float v = tv[mt][nt][r]; tv[mt][nt][r] = (EB_VAR & 1) ? (v >= 0.f ? v : v * p.slope) : fmaxf(v, v * p.slope); }     // LeakyReLU, 0 <= slope <= 1 (checked by the launcher)
           const int pos = 16 * nt + l15;
           if (save && pos < L.len) *reinterpret_cast<f32x4e*>(tsave + (L.rowbase + (long long)pos * L.rowstep) * 32 + 16 * mt + 4 * g) = tv[mt][nt];
         }
+      if (save) asm volatile("s_nop 1" : "+v"(tv[0][0]), "+v"(tv[0][1]), "+v"(tv[1][0]), "+v"(tv[1][1]));     // (same store-data hazard as below)
     }
     // ---- stage 2: y[n'][x] = lrelu(sum_k W2[n'][k] t[x][k]), K = 32 = one K step.  The lane (position, g) already HOLDS eight of its position's channels
     //      (16 mt + 4 g + r): they are its B operand as they stand once the pack stores W2's columns in that order (k slot 8 g + 4 mt + r <-> channel 16 mt + 4 g + r) ----
@@ -339,8 +343,13 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
         for (int h = 0; h < 2; ++h) {
           f32x4e v = o[h][nt];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], v[r] * p.slope);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, v), rsY, yoff[nt], __builtin_amdgcn_readfirstlane(mp * ychunk + 64 * h), 0);
+          for (int r = 0; r < 4; ++r) v[r] = (EB_VAR & 1) ? (v[r] >= 0.f ? v[r] : v[r] * p.slope) : fmaxf(v[r], v[r] * p.slope);
+          if (EB_VAR & 2) { if (yoff[nt] != EOOB) *reinterpret_cast<f32x4e*>(reinterpret_cast<char*>(p.Y) + (long long)yoff[nt] + (long long)mp * ychunk + 64 * h) = v; }
+          else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4e, v), rsY, yoff[nt], __builtin_amdgcn_readfirstlane(mp * ychunk + 64 * h), 0);
+          // A 16-B store (SGPR offset) followed by a write of its data registers needs a wait state; the compiler pads it for instructions it can see, but the next
+          // writer may be one of the asm MFMAs (their accumulators are allocated over dead registers).  Found the hard way: ~10 wrong values per 3 M.  Holding the
+          // data registers live across a one-cycle wait closes it.
+          asm volatile("s_nop 1" : "+v"(v));
         }
     }
     if (!more) break;

@@ -5,7 +5,7 @@ mkdir -p gpurun_out/r3
 python -m pytest tests/test_gpu_b3_accuracy.py tests/test_gpu_distgssr.py tests/test_gpu_bwd_ops.py -x -q -m gpu > gpurun_out/r3/c9_tests.log 2>&1 || { tail -40 gpurun_out/r3/c9_tests.log; exit 1; }
 tail -2 gpurun_out/r3/c9_tests.log
 python tools/epi_time.py > gpurun_out/r3/c9_epi_abl.log 2>&1
-for t in a1 a8 a16 a63; do LFSR_HIP_LIB=$PWD/_diag/liblfsr_epi_b3_$t.so python tools/epi_time.py >> gpurun_out/r3/c9_epi_abl.log 2>&1; done
+for t in a1 a8 a16 a63 v4; do LFSR_HIP_LIB=$PWD/_diag/liblfsr_epi_b3_$t.so python tools/epi_time.py >> gpurun_out/r3/c9_epi_abl.log 2>&1; done
 LFSR_EPI=wino python tools/epi_time.py >> gpurun_out/r3/c9_epi_abl.log 2>&1
 python tools/epi_time.py >> gpurun_out/r3/c9_epi_abl.log 2>&1
 grep -v amdgpu.ids gpurun_out/r3/c9_epi_abl.log
