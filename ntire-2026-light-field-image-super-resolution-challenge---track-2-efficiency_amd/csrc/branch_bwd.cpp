@@ -38,8 +38,9 @@ int mask_lrelu(const float* dy, int dy_stride, int dy_choff, const float* y, int
 
 // AngConv: y = PixelShuffle_A(lrelu(W2 . a16)), a16 = lrelu(W0 (*) x) (A x A, stride A).  dcat: dLoss/dy inside a VCL buffer (16 channels at dc_choff).
 // dx += ; dw0 (16,64,A,A), dw2 (16 A^2,16,1,1) overwritten.  dA16: (B h w, 16) scratch; P: partial-slab scratch of >= lfsr_branch_bwd_partial_floats.
-int lfsr_ang_branch_bwd(const float* dcat, int dc_stride, int dc_choff, const float* xin, const float* a16, const float* w0_packed, const float* w0T_packed,
-                        const float* w2T_packed, float* dx, float* dw0, float* dw2, float* dA16, float* P, int B, int A, int h, int w, float slope, hipStream_t st) {
+// Two parts so that a caller may run part 1 (everything up to dA16 and both weight gradients) on another stream than part 2 (the read-modify-write of dx).
+int lfsr_ang_branch_bwd_p1(const float* dcat, int dc_stride, int dc_choff, const float* xin, const float* a16, const float* w2T_packed, float* dw0, float* dw2,
+                           float* dA16, float* P, int B, int A, int h, int w, float slope, hipStream_t st) {
   const int AA = A * A, nlr = B * h * w;
   int rc;
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
@@ -54,68 +55,100 @@ int lfsr_ang_branch_bwd(const float* dcat, int dc_stride, int dc_choff, const fl
   }
   RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_ANG, dA16, 16, 0, xin, 64, 0, P, nlr, 16, 64, A, h, w, AA, st));
   RC(lfsr_wgrad_reduce(P, lfsr_wgrad_splits(nlr, AA, 64), nullptr, 0, dw0, 16, 64, AA, 0, 0, 0, 0, 0, st));
-  {
-    LfsrGemm q{};
-    q.in_mode = LFSR_IN_SAME; q.out_mode = LFSR_OUT_VIEWS; q.cin = 16; q.X = dA16; q.x_stride = 16; q.Wp = w0T_packed;
-    q.Y = dx; q.y_stride = 64; q.R1 = dx; q.r1_stride = 64;
-    q.M = nlr; q.N = AA * 64; q.A = A; q.h = h; q.w = w; q.ntaps = 1; q.CH = 64;
-    int rc4 = lfsr_ang0_dgrad_launch(dA16, w0_packed, dx, 64, 0, B, A, h, w, st);   // streaming read-modify-write form; else the gather-GEMM
-    if (rc4 == LFSR_E_ARG) rc4 = lfsr_bwd_gemm(q, st);
-    RC(rc4);
-  }
 #undef RC
   return LFSR_OK;
+}
+
+int lfsr_ang_branch_bwd_p2(const float* dA16, const float* w0_packed, const float* w0T_packed, float* dx, int B, int A, int h, int w, hipStream_t st) {
+  const int AA = A * A, nlr = B * h * w;
+  LfsrGemm q{};
+  q.in_mode = LFSR_IN_SAME; q.out_mode = LFSR_OUT_VIEWS; q.cin = 16; q.X = dA16; q.x_stride = 16; q.Wp = w0T_packed;
+  q.Y = dx; q.y_stride = 64; q.R1 = dx; q.r1_stride = 64;
+  q.M = nlr; q.N = AA * 64; q.A = A; q.h = h; q.w = w; q.ntaps = 1; q.CH = 64;
+  int rc4 = lfsr_ang0_dgrad_launch(dA16, w0_packed, dx, 64, 0, B, A, h, w, st);   // streaming read-modify-write form; else the gather-GEMM
+  if (rc4 == LFSR_E_ARG) rc4 = lfsr_bwd_gemm(q, st);
+  return rc4;
+}
+
+int lfsr_ang_branch_bwd(const float* dcat, int dc_stride, int dc_choff, const float* xin, const float* a16, const float* w0_packed, const float* w0T_packed,
+                        const float* w2T_packed, float* dx, float* dw0, float* dw2, float* dA16, float* P, int B, int A, int h, int w, float slope, hipStream_t st) {
+  const int rc = lfsr_ang_branch_bwd_p1(dcat, dc_stride, dc_choff, xin, a16, w2T_packed, dw0, dw2, dA16, P, B, A, h, w, slope, st);
+  return rc ? rc : lfsr_ang_branch_bwd_p2(dA16, w0_packed, w0T_packed, dx, B, A, h, w, st);
 }
 
 // EPIConv on the tensor (horizontal) and on its transpose (vertical), shared weights: y_h / y_v = PixelShuffle1D_A(lrelu(W2 . e)), e = lrelu(W0 (*) x)
 // (1 x A^2, stride A along the EPI line).  dcat: dLoss/dy_h at choff_h, dLoss/dy_v at choff_v (32 channels each) of one VCL buffer.
 // dx += ; dw0 (32,64,1,A^2), dw2 (32 A,32,1,1) overwritten (both passes summed).  dEh, dEv: (B A h w, 32) scratch; P[4]: partial-slab scratch.
-int lfsr_epi_branch_bwd(const float* dcat, int dc_stride, int choff_h, int choff_v, const float* xin, const float* eh, const float* ev,
-                        const float* w0_packed, const float* w0T_packed, const float* w2T_packed, float* dx, float* dw0, float* dw2,
-                        float* dEh, float* dEv, float* const P[4], int B, int A, int h, int w, float slope, hipStream_t st) {
-  const int AA = A * A, nepi = B * A * h * w;
-  const long long npix = (long long)B * AA * h * w;
+// Three parts: p1 = stage 2 of both passes (dEh, dEv, dw2), p2d = the read-modify-write of dx, p2w = EPIConv.0's weight gradient (reads dEh, dEv and x only).
+int lfsr_epi_branch_bwd_p1(const float* dcat, int dc_stride, int choff_h, int choff_v, const float* eh, const float* ev, const float* w2T_packed, float* dw2,
+                           float* dEh, float* dEv, float* const P[4], int B, int A, int h, int w, float slope, hipStream_t st) {
+  const int nepi = B * A * h * w;
   int rc;
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
-  // the two passes share EPIConv.0's weights: where the EPI-line kernel applies, ONE weight-gradient launch covers both (one slab per block instead of
-  // two sets), after both passes' dE exist; else the gather form per pass
-  const char* wsel = getenv("LFSR_WGRAD_EPI");
-  const bool epi_merged = lfsr_wgrad_epi0_blocks(B, A, h, w, 2) > 0 && A == 5 && h <= 32 && w <= 32 && npix * 64 * 4 < (1LL << 31) && !(wsel && wsel[0] == 'g');
-  int epi_slabs[2] = {0, 0};
   for (int vert = 0; vert < 2; ++vert) {
     const float* E = vert ? ev : eh;
     float* dE = vert ? dEv : dEh;
     const int choff = vert ? choff_v : choff_h;
     float* Pa = P[vert ? 2 : 0];   // EPIConv.2 partials
-    float* Pb = P[vert ? 3 : 1];   // EPIConv.0 partials
     RC(lfsr_wgrad_launch(vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H, LFSR_IN_SAME, dcat, dc_stride, choff, E, 32, 0, Pa, nepi, 32, 32, A, h, w, A, st));
     LfsrGemm q{};
     q.in_mode = vert ? LFSR_IN_CHK_V : LFSR_IN_CHK_H; q.out_mode = LFSR_OUT_SAME; q.cin = 32; q.X = dcat; q.x_stride = dc_stride; q.x_choff = choff;
     q.Wp = w2T_packed; q.Y = dE; q.y_stride = 32; q.Mk = E; q.mk_stride = 32; q.mk_slope = slope;
     q.M = nepi; q.N = 32; q.A = A; q.h = h; q.w = w; q.ntaps = A; q.CH = 32;
     RC(lfsr_bwd_gemm(q, st));
-    if (!epi_merged) {
-      RC(lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, dE, 32, 0, xin, 64, 0, Pb, nepi, 32, 64, A, h, w, AA, st));
-      epi_slabs[vert] = lfsr_wgrad_splits(nepi, AA, 64);
-    }
+  }
+  RC(lfsr_wgrad_reduce(P[0], lfsr_wgrad_splits(nepi, A, 32), P[2], lfsr_wgrad_splits(nepi, A, 32), dw2, 32 * A, 32, A, 0, 32, 0, 0, 1, st));
+#undef RC
+  return LFSR_OK;
+}
+
+int lfsr_epi_branch_bwd_p2d(const float* dEh, const float* dEv, const float* w0_packed, const float* w0T_packed, float* dx, int B, int A, int h, int w, hipStream_t st) {
+  const int nepi = B * A * h * w;
+  for (int vert = 0; vert < 2; ++vert) {
+    const float* dE = vert ? dEv : dEh;
     LfsrGemm r{};
     r.in_mode = vert ? LFSR_IN_LINE_V : LFSR_IN_LINE_H; r.out_mode = vert ? LFSR_OUT_EPIV : LFSR_OUT_EPIH; r.cin = 32; r.X = dE; r.x_stride = 32;
     r.Wp = w0T_packed; r.Y = dx; r.y_stride = 64; r.R1 = dx; r.r1_stride = 64;
     r.M = nepi; r.N = A * 64; r.A = A; r.h = h; r.w = w; r.ntaps = A; r.CH = 64;
-    {   // EPIConv.0 data gradient (accumulates into dx): EPI-line kernel where it applies, else the gather-GEMM
-      int rc3 = lfsr_epi0_dgrad_launch(dE, w0_packed, dx, 64, 0, B, A, h, w, vert, st);
-      if (rc3 == LFSR_E_ARG) rc3 = lfsr_bwd_gemm(r, st);
-      RC(rc3);
-    }
+    // EPIConv.0 data gradient (accumulates into dx): EPI-line kernel where it applies, else the gather-GEMM
+    int rc3 = lfsr_epi0_dgrad_launch(dE, w0_packed, dx, 64, 0, B, A, h, w, vert, st);
+    if (rc3 == LFSR_E_ARG) rc3 = lfsr_bwd_gemm(r, st);
+    if (rc3) return rc3;
   }
+  return LFSR_OK;
+}
+
+int lfsr_epi_branch_bwd_p2w(const float* dEh, const float* dEv, const float* xin, float* dw0, float* const P[4], int B, int A, int h, int w, hipStream_t st) {
+  const int AA = A * A, nepi = B * A * h * w;
+  const long long npix = (long long)B * AA * h * w;
+  int rc;
+#define RC(call) do { rc = (call); if (rc) return rc; } while (0)
+  // the two passes share EPIConv.0's weights: where the EPI-line kernel applies, ONE weight-gradient launch covers both (one slab per block instead of
+  // two sets); else the gather form per pass
+  const char* wsel = getenv("LFSR_WGRAD_EPI");
+  const bool epi_merged = lfsr_wgrad_epi0_blocks(B, A, h, w, 2) > 0 && A == 5 && h <= 32 && w <= 32 && npix * 64 * 4 < (1LL << 31) && !(wsel && wsel[0] == 'g');
+  int epi_slabs[2] = {0, 0};
   if (epi_merged) {
     RC(lfsr_wgrad_epi0_launch(dEh, dEv, xin, 64, 0, P[1], B, A, h, w, 2, st));
     epi_slabs[0] = lfsr_wgrad_epi0_blocks(B, A, h, w, 2);
+  } else {
+    for (int vert = 0; vert < 2; ++vert) {
+      RC(lfsr_wgrad_launch(LFSR_IN_SAME, vert ? LFSR_IN_EPIV : LFSR_IN_EPIH, vert ? dEv : dEh, 32, 0, xin, 64, 0, P[vert ? 3 : 1], nepi, 32, 64, A, h, w, AA, st));
+      epi_slabs[vert] = lfsr_wgrad_splits(nepi, AA, 64);
+    }
   }
-  RC(lfsr_wgrad_reduce(P[0], lfsr_wgrad_splits(nepi, A, 32), P[2], lfsr_wgrad_splits(nepi, A, 32), dw2, 32 * A, 32, A, 0, 32, 0, 0, 1, st));
   RC(lfsr_wgrad_reduce(P[1], epi_slabs[0], epi_slabs[1] ? P[3] : nullptr, epi_slabs[1], dw0, 32, 64, AA, 0, 0, 0, 0, 0, st));
 #undef RC
   return LFSR_OK;
+}
+
+int lfsr_epi_branch_bwd(const float* dcat, int dc_stride, int choff_h, int choff_v, const float* xin, const float* eh, const float* ev,
+                        const float* w0_packed, const float* w0T_packed, const float* w2T_packed, float* dx, float* dw0, float* dw2,
+                        float* dEh, float* dEv, float* const P[4], int B, int A, int h, int w, float slope, hipStream_t st) {
+  int rc = lfsr_epi_branch_bwd_p1(dcat, dc_stride, choff_h, choff_v, eh, ev, w2T_packed, dw2, dEh, dEv, P, B, A, h, w, slope, st);
+  if (!rc) rc = lfsr_epi_branch_bwd_p2d(dEh, dEv, w0_packed, w0T_packed, dx, B, A, h, w, st);
+  if (!rc) rc = lfsr_epi_branch_bwd_p2w(dEh, dEv, xin, dw0, P, B, A, h, w, st);
+  return rc;
 }
 
 size_t lfsr_branch_bwd_partial_floats(int B, int A, int h, int w) {

@@ -39,7 +39,7 @@ struct lfsr_distgssr {
   size_t table_cap = 0;
   // backward: the weight gradient of a 3x3 layer runs on a side stream beside the layer's data gradient (both read the same dY); created on first use
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
   bool profiling = false;
   struct Ev { int cls; hipEvent_t a, b; };
   bool profile_all = true;
@@ -113,6 +113,8 @@ void lfsr_distgssr_destroy(lfsr_distgssr* c) {
   if (c->table_dev) (void)hipFree(c->table_dev);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
@@ -359,7 +361,7 @@ struct TrainWs {
   float *F0, *D;
   std::vector<float*> S1, CAT, A16, EH, EV, FZ, OUT, GOUT;
   // backward scratch
-  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *dE32V, *G16, *XG9, *P[4], *small;
+  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *dE32V, *G16, *XG9, *P[4], *PA, *small;   // PA: partial slabs of the angular branch (its own: it may run beside the epipolar one)
   size_t pfloats;
   size_t total;
 };
@@ -399,6 +401,7 @@ void train_layout(const lfsr_distgssr* c, int B, int h, int w, float* base, Trai
   t.dA16 = take(nlr * 16); t.dE32 = take(nepi * 32); t.dE32V = take(nepi * 32); t.G16 = take(npix * 16); t.XG9 = take(npix * 16);
   t.pfloats = max_partial_floats(c, B, h, w);
   for (int i = 0; i < 4; ++i) t.P[i] = take(t.pfloats);
+  t.PA = take(lfsr_branch_bwd_partial_floats(B, c->A, h, w));
   t.small = take(64 * 1024);
   t.total = o;
 }
@@ -511,18 +514,23 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   // gradient's blocks could fill them.  MEASURED NEGATIVE (round 3, two runs each in one call, profiles/r03_logs/c6_overlap.txt): 25.3 ms with the side stream against
   // 24.5 ms on one stream -- both kernels are persistent one-block-per-CU grids (159 KB / 115 KB of LDS: never co-resident on a CU), so interleaving their blocks only
   // lengthens both.  Kept as an option: LFSR_BWD_OVERLAP=1.  Every wgrad3 is followed by its dgrad3 below.  Not under stream capture.
-  bool overlap = false;
+  bool overlap = false, overlap_br = false, overlap_pw = false;
   {
+    // LFSR_BWD_OVERLAP: bit 0 = the 3x3 weight gradients beside their data gradients (measured negative, off); bit 1 = the small launches of the angular branch's
+    // backward beside those of the epipolar branch, and EPIConv.0's weight gradient beside the read-modify-write chain of dx (default on: unset = "2")
     const char* osel = getenv("LFSR_BWD_OVERLAP");
+    const int omode = osel ? atoi(osel) : 2;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (osel && osel[0] == '1' && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+    if (omode && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
       if (!c->side) {
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
-        if (c->side && (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)) {
-          (void)hipStreamDestroy(c->side); c->side = nullptr;
-        }
+        bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { if (c->side) (void)hipStreamDestroy(c->side); c->side = nullptr; }
       }
-      overlap = c->side != nullptr;
+      overlap = c->side != nullptr && (omode & 1);
+      overlap_br = c->side != nullptr && (omode & 2);
+      overlap_pw = c->side != nullptr && (omode & 4);      // fuse.0's weight gradient beside its data gradient (A/B)
     }
   }
   bool forked = false;
@@ -589,12 +597,22 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
       RC(wgrad3(p + "fuse.2.weight", t.FZ[i], gy, 64));
       RC(dgrad3(gy, 64, p + "fuse.2.weight", t.dF, nullptr, nullptr, t.FZ[i], 64));
       // fuse.0 : FZ = lrelu(1x1(CAT))
-      {   // streaming kernel (every row of dF and CAT read once, one slab per block); else the generic split-K kernel
-        int rc5 = lfsr_wgrad_pw144_launch(t.dF, 64, 0, t.CAT[i], 144, 0, t.P[0], npix, st);
+      {   // streaming kernel (every row of dF and CAT read once, one slab per block); else the generic split-K kernel.  (overlap_pw: on the side stream beside the data gradient)
+        hipStream_t ws = st;
+        if (overlap_pw) {
+          if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return LFSR_E_ARG;
+          ws = c->side;
+        }
+        float* Pw = t.PA;                 // (its own slab buffer: P[0] belongs to the main stream's weight gradients)
+        int rc5 = lfsr_wgrad_pw144_launch(t.dF, 64, 0, t.CAT[i], 144, 0, Pw, npix, ws);
         int slabs = lfsr_wgrad_pw144_blocks(npix);
-        if (rc5 == LFSR_E_ARG) { rc5 = lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.dF, 64, 0, t.CAT[i], 144, 0, t.P[0], npix, 64, 144, 1, h, w, 1, st); slabs = lfsr_wgrad_splits(npix, 1, 144); }
+        if (rc5 == LFSR_E_ARG) {
+          ws = st; Pw = t.P[0];           // generic split-K kernel: larger slabs, one stream
+          rc5 = lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.dF, 64, 0, t.CAT[i], 144, 0, Pw, npix, 64, 144, 1, h, w, 1, ws); slabs = lfsr_wgrad_splits(npix, 1, 144);
+        }
         RC(rc5);
-        RC(lfsr_wgrad_reduce(t.P[0], slabs, nullptr, 0, G(p + "fuse.0.weight"), 64, 144, 1, 0, 0, 0, 0, 0, st));
+        RC(lfsr_wgrad_reduce(Pw, slabs, nullptr, 0, G(p + "fuse.0.weight"), 64, 144, 1, 0, 0, 0, 0, 0, ws));
+        if (overlap_pw && hipEventRecord(c->ev_join, c->side) != hipSuccess) return LFSR_E_ARG;
       }
       {
         LfsrGemm q{};
@@ -602,6 +620,7 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         q.Y = t.dCAT; q.y_stride = 144; q.Mk = t.CAT[i]; q.mk_stride = 144; q.mk_slope = L;
         q.M = npix; q.N = 144; q.A = 1; q.h = 1; q.w = 1; q.ntaps = 1; q.CH = 144;
         RC(lfsr_bwd_gemm(q, st));
+        if (overlap_pw && hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) return LFSR_E_ARG;
       }
       // SpaConv : CAT[0:64] = lrelu(conv(S1)), S1 = lrelu(conv(Xin))
       RC(wgrad3(p + "SpaConv.2.weight", t.S1[i], t.dCAT, 144));
@@ -609,11 +628,30 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
       RC(wgrad3(p + "SpaConv.0.weight", Xin, t.dS1, 64));
       RC(dgrad3(t.dS1, 64, p + "SpaConv.0.weight", gx, gy, nullptr, nullptr, 0));          // gx = gy (block skip) + dSpa
       // AngConv : CAT[64:80] = PS(lrelu(1x1(A16))), A16 = lrelu(convAxA(Xin))          (branch_bwd.cpp; also exported as lfsr_angconv_bwd)
-      RC(lfsr_ang_branch_bwd(t.dCAT, 144, 64, Xin, t.A16[i], c->w(p + "AngConv.0.weight"), c->wT(p + "AngConv.0.weight"), c->wT(p + "AngConv.2.weight"),
-                             gx, G(p + "AngConv.0.weight"), G(p + "AngConv.2.weight"), t.dA16, t.P[0], B, A, h, w, L, st));
       // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)                 (lfsr_epiconv_hv_bwd)
-      RC(lfsr_epi_branch_bwd(t.dCAT, 144, 80, 112, Xin, t.EH[i], t.EV[i], c->w(p + "EPIConv.0.weight"), c->wT(p + "EPIConv.0.weight"), c->wT(p + "EPIConv.2.weight"),
-                             gx, G(p + "EPIConv.0.weight"), G(p + "EPIConv.2.weight"), t.dE32, t.dE32V, t.P, B, A, h, w, L, st));
+      const float *wa0 = c->w(p + "AngConv.0.weight"), *wa0T = c->wT(p + "AngConv.0.weight"), *wa2T = c->wT(p + "AngConv.2.weight");
+      const float *we0 = c->w(p + "EPIConv.0.weight"), *we0T = c->wT(p + "EPIConv.0.weight"), *we2T = c->wT(p + "EPIConv.2.weight");
+      if (!overlap_br) {
+        RC(lfsr_ang_branch_bwd(t.dCAT, 144, 64, Xin, t.A16[i], wa0, wa0T, wa2T, gx, G(p + "AngConv.0.weight"), G(p + "AngConv.2.weight"), t.dA16, t.PA, B, A, h, w, L, st));
+        RC(lfsr_epi_branch_bwd(t.dCAT, 144, 80, 112, Xin, t.EH[i], t.EV[i], we0, we0T, we2T, gx, G(p + "EPIConv.0.weight"), G(p + "EPIConv.2.weight"), t.dE32, t.dE32V, t.P,
+                               B, A, h, w, L, st));
+      } else {
+        // Two streams.  The launches of these branches are small (18-30 us each, a few hundred blocks): seven of them per block in a row leave most of the chip idle.
+        //   side:  [ang p1: AngConv.2 wgrad, AngConv.2 dgrad -> dA16, AngConv.0 wgrad] ......... wait(ev_b) [EPIConv.0 wgrad (reads dE_h, dE_v, x)]
+        //   main:  [epi p1: EPIConv.2 wgrad + dgrad, both passes -> dE_h, dE_v] rec(ev_b) wait(ev_a) [AngConv.0 dgrad: dx +=] [EPIConv.0 dgrad H, V: dx +=] wait(ev_join)
+        // The three read-modify-writes of dx stay in one stream, in the order of the one-stream form (same bits).
+        if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return LFSR_E_ARG;
+        RC(lfsr_ang_branch_bwd_p1(t.dCAT, 144, 64, Xin, t.A16[i], wa2T, G(p + "AngConv.0.weight"), G(p + "AngConv.2.weight"), t.dA16, t.PA, B, A, h, w, L, c->side));
+        if (hipEventRecord(c->ev_a, c->side) != hipSuccess) return LFSR_E_ARG;
+        RC(lfsr_epi_branch_bwd_p1(t.dCAT, 144, 80, 112, t.EH[i], t.EV[i], we2T, G(p + "EPIConv.2.weight"), t.dE32, t.dE32V, t.P, B, A, h, w, L, st));
+        if (hipEventRecord(c->ev_b, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_b, 0) != hipSuccess) return LFSR_E_ARG;
+        RC(lfsr_epi_branch_bwd_p2w(t.dE32, t.dE32V, Xin, G(p + "EPIConv.0.weight"), t.P, B, A, h, w, c->side));
+        if (hipEventRecord(c->ev_join, c->side) != hipSuccess) return LFSR_E_ARG;
+        if (hipStreamWaitEvent(st, c->ev_a, 0) != hipSuccess) return LFSR_E_ARG;
+        RC(lfsr_ang_branch_bwd_p2(t.dA16, wa0, wa0T, gx, B, A, h, w, st));
+        RC(lfsr_epi_branch_bwd_p2d(t.dE32, t.dE32V, we0, we0T, gx, B, A, h, w, st));
+        if (hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) return LFSR_E_ARG;
+      }
       gy = gx;
     }
     // group skip: grad at the group's input = (through the blocks) + dG

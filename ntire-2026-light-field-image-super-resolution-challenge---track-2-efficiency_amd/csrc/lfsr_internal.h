@@ -193,3 +193,11 @@ int lfsr_ang_branch_bwd(const float* dcat, int dc_stride, int dc_choff, const fl
 int lfsr_epi_branch_bwd(const float* dcat, int dc_stride, int choff_h, int choff_v, const float* xin, const float* eh, const float* ev,
                         const float* w0_packed, const float* w0T_packed, const float* w2T_packed, float* dx, float* dw0, float* dw2,
                         float* dEh, float* dEv, float* const P[4], int B, int A, int h, int w, float slope, hipStream_t st);
+// ... the same in parts, for callers that run independent parts on two streams (lfsr_distgssr_backward): p1 = everything but the read-modify-write of dx
+int lfsr_ang_branch_bwd_p1(const float* dcat, int dc_stride, int dc_choff, const float* xin, const float* a16, const float* w2T_packed, float* dw0, float* dw2,
+                           float* dA16, float* P, int B, int A, int h, int w, float slope, hipStream_t st);
+int lfsr_ang_branch_bwd_p2(const float* dA16, const float* w0_packed, const float* w0T_packed, float* dx, int B, int A, int h, int w, hipStream_t st);
+int lfsr_epi_branch_bwd_p1(const float* dcat, int dc_stride, int choff_h, int choff_v, const float* eh, const float* ev, const float* w2T_packed, float* dw2,
+                           float* dEh, float* dEv, float* const P[4], int B, int A, int h, int w, float slope, hipStream_t st);
+int lfsr_epi_branch_bwd_p2d(const float* dEh, const float* dEv, const float* w0_packed, const float* w0T_packed, float* dx, int B, int A, int h, int w, hipStream_t st);
+int lfsr_epi_branch_bwd_p2w(const float* dEh, const float* dEv, const float* xin, float* dw0, float* const P[4], int B, int A, int h, int w, hipStream_t st);
