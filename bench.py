@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-split-check", action="store_true",
                     help="skip the B = 1 re-runs of the batch-independence check (profiling passes: keeps every launch of a kernel the same size)")
     ap.add_argument("--rank-timeout", type=float, default=900.0, help="--gpus N self-launch: seconds after which a still-running rank is killed (with the others) and the run fails")
+    ap.add_argument("--arithmetic", choices=["default", "f32"], default="default",
+                    help="default: the GEMMs that have an exact-three-term-bf16 form run it (EPI branch, fuse.0, the transformers' linears / FFN / tail); "
+                         "f32: every GEMM on fp32 MFMA (lfsr_set_arithmetic)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the configs[2] / [3] / [4] lines (EPIT, training step, LFT scene) of the default run")
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: 32 infer, 8 train / epit / lft)")
     ap.add_argument("--workload", choices=["infer", "train", "epit", "lft"], default="infer",
@@ -330,7 +333,9 @@ def bench_model(args, rank, world, dev, dist):
         # the arithmetic the transformer GEMMs run in (rowgemm_b3.hip / ffn_b3.hip / up_tail.hip): fp32 operands split EXACTLY into three bf16 terms, six
         # products on the bf16 MFMA pipe, fp32 accumulation -- error against fp64 below the fp32-MFMA kernels' (tools/b3_accuracy.py); LFSR_ROWGEMM=f32
         # LFSR_FFN=f32 LFSR_UPTAIL=v2 select the fp32-MFMA kernels
-        f32_sel = [os.environ.get("LFSR_ROWGEMM", "")[:1] in ("f", "1"), os.environ.get("LFSR_FFN", "")[:1] == "f", os.environ.get("LFSR_UPTAIL", "")[:1] == "v"]
+        lab = "LFSR_LAB" in os.environ      # (the A/B selectors are live only then)
+        f32_sel = [args.arithmetic == "f32" or (lab and os.environ.get("LFSR_ROWGEMM", "")[:1] in ("f", "1")), args.arithmetic == "f32" or (lab and os.environ.get("LFSR_FFN", "")[:1] == "f"),
+                   args.arithmetic == "f32" or (lab and os.environ.get("LFSR_UPTAIL", "")[:1] == "v")]
         line["dtype"] = "f32" if all(f32_sel) else "f32 (linear / FFN / tail GEMMs: fp32 operands as three exact bf16 terms on the bf16 MFMA pipe, fp32 accumulation; 3x3 convs and attention: fp32 MFMA)"
         line["config"]["gemm_arithmetic"] = {"rowgemm": "f32" if f32_sel[0] else "bf16x3", "ffn": "f32" if f32_sel[1] else "bf16x3", "up_tail": "f32" if f32_sel[2] else "bf16x3"}
         print(json.dumps(line), flush=True)
@@ -378,7 +383,6 @@ def other_workloads(dev, budget_steps=(20, 10, 8)):
     from lfsr_amd import capi
     from lfsr_amd.synth import synth_input, synth_state_dict
     meta_all = json.load(open(os.path.join(ROOT, "tests", "golden", "models.json")))["models"]
-    F32_ENV = {"LFSR_ROWGEMM": "f32", "LFSR_FFN": "f32", "LFSR_UPTAIL": "v2"}
     out = []
 
     def timed(step, warm, steps):
@@ -414,17 +418,13 @@ def other_workloads(dev, budget_steps=(20, 10, 8)):
         e["by_operator_ms_per_step"] = {f"{k[0]}({k[1]},{k[2]})": v[0] / nprof for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:8]}
         return e
 
-    def set_env(env):
-        for k in F32_ENV:
-            os.environ.pop(k, None)
-        os.environ.update(env)
 
     # ---- configs[2] EPIT B = 8 and configs[4] LFT scene: both arithmetic selections (read when the runtime is built and at every launch) ----
     for name, key, steps in (("epit", "EPIT", budget_steps[0]), ("lft", "LFT", budget_steps[2])):
         sd = synth_state_dict([(k, tuple(sh)) for k, sh in meta_all[key]["full"]["spec"]], seed=0)
         lines = {}
-        for arith, env in (("bf16x3", {}), ("f32", F32_ENV)):
-            set_env(env)
+        for arith in ("bf16x3", "f32"):
+            capi.set_arithmetic(capi.ARITH_F32 if arith == "f32" else capi.ARITH_DEFAULT)
             rt = capi.ModelRuntime(name, A, S, 5 if name == "epit" else 4, 64)
             rt.load_state([(k, torch.from_numpy(v).to(dev)) for k, v in sd.items()], dev)
             if name == "epit":
@@ -437,7 +437,7 @@ def other_workloads(dev, budget_steps=(20, 10, 8)):
             sec = timed(step, 3, steps)
             lines[arith] = {"value": per_step / sec, "ms_per_step": sec * 1e3, "dominant": dominant(step, npix, arith == "f32")}
             del rt
-        set_env({})
+        capi.set_arithmetic(capi.ARITH_DEFAULT)
         b3, f32 = lines["bf16x3"], lines["f32"]
         out.append({"config": "configs[2]: EPIT 5x5 x4 inference, batch 8 patches, 1 GPU" if name == "epit" else
                               "configs[4]: LFT 5x5 x4 full-scene inference (5x5x128x128 -> 64 patches via LFdivide / LFintegrate, minibatch 32), 1 GPU",
@@ -518,21 +518,18 @@ def bench_infer(args, rank, world, dev, dist):
     rt.profile(3)
     el, y = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
     prof = rt.profile_read()
-    # the same timed loop with every GEMM of the forward on fp32 MFMA (LFSR_EPI=wino: the F(2,5) fp32 kernel of the EPI branch; LFSR_ROWGEMM=f32: fuse.0 on the
+    # the same timed loop with every GEMM of the forward on fp32 MFMA (lfsr_set_arithmetic(LFSR_ARITH_F32): the F(2,5) fp32 kernel of the EPI branch, fuse.0 on the
     # fp32 row-GEMM): printed beside the headline whenever the headline uses the exact three-term bf16 form for those two operators
-    user_sel = {k: os.environ.get(k) for k in ("LFSR_EPI", "LFSR_ROWGEMM")}
-    b3_ops = [k for k, v in user_sel.items() if not (v and v[:1] in ("w", "d", "f", "g", "1"))]
+    lab = "LFSR_LAB" in os.environ          # (the library's A/B selectors are live only then)
+    user_sel = {k: (os.environ.get(k) if lab else None) for k in ("LFSR_EPI", "LFSR_ROWGEMM")}
+    b3_ops = [] if args.arithmetic == "f32" else [k for k, v in user_sel.items() if not (v and v[:1] in ("w", "d", "f", "g", "1"))]
     el_f32 = None
     if b3_ops:
-        os.environ.update(LFSR_EPI="wino", LFSR_ROWGEMM="f32")
+        capi.set_arithmetic(capi.ARITH_F32)
         for _ in range(2):
             rt.forward(x)
         el_f32, _ = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
-        for k, v in user_sel.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        capi.set_arithmetic(capi.ARITH_DEFAULT)
         rt.forward(x)
     rt.profile(1)
     nb = 3
@@ -578,7 +575,7 @@ def bench_infer(args, rank, world, dev, dist):
             line["config"]["gemm_arithmetic"] = {"conv3x3": "f32", "epiconv": "bf16x3" if "LFSR_EPI" in b3_ops else "f32", "fuse.0": "bf16x3" if "LFSR_ROWGEMM" in b3_ops else "f32",
                                                  "angconv": "f32", "head": "f32"}
             line["all_fp32_mfma"] = {"value": world * B * args.steps / el_f32, "unit": "patches/s", "ms_per_step": el_f32 / args.steps * 1e3, "dtype": "f32",
-                                     "selection": "LFSR_EPI=wino LFSR_ROWGEMM=f32 (same process, same weights, timed right after the headline loop)"}
+                                     "selection": "lfsr_set_arithmetic(LFSR_ARITH_F32) (same process, same weights, timed right after the headline loop)"}
         line["roofline"] = {
             "bound": "mfma", "achieved": exec_flop / conv_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": max(mfma_floor, hbm_floor) / conv_s, "traffic": traffic, "traffic_source": tsrc,
@@ -655,6 +652,9 @@ def main():
         time.sleep(600 if kind == "fail" else 0)
         sys.exit(0)
     rank, world, dev, dist = init_rank(args)
+    if args.arithmetic == "f32":
+        from lfsr_amd import capi
+        capi.set_arithmetic(capi.ARITH_F32)
     if args.workload == "train":
         return bench_train(args, rank, world, dev, dist)
     if args.workload in ("epit", "lft"):

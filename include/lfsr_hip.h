@@ -364,6 +364,15 @@ int lfsr_epiconv_hv_bwd(const float* dy, int dy_stride, int choff_h, int choff_v
                         const float* x, const float* e_h, const float* e_v, const float* w0, const float* w2,
                         float* dx, float* dw0, float* dw2, float* workspace, size_t workspace_floats, int B, int A, int h, int w, float slope, void* stream);
 
+/* ---- arithmetic of the GEMMs that exist in two forms (DistgSSR's EPI branch and fuse.0; the transformers' linears, fused FFN and up-sampling tail) ----
+ * LFSR_ARITH_DEFAULT: fp32 operands carried EXACTLY as three bf16 terms on the bf16 MFMA pipe, six products, fp32 accumulation (error against fp64 not above the
+ * fp32-MFMA kernels': tests/test_gpu_b3_accuracy.py); LFSR_ARITH_F32: every GEMM on fp32 MFMA.  Process-wide, read at every launch; the 3x3 convs, the angular
+ * branch and the attention kernels compute on fp32 MFMA either way.  The reference computes all of these layers with stock fp32 torch ops. */
+#define LFSR_ARITH_DEFAULT 0
+#define LFSR_ARITH_F32 1
+int lfsr_set_arithmetic(int mode);
+int lfsr_get_arithmetic(void);
+
 /* ---- operator-level timing hooks (measurement aid; the reference times whole forwards only: check_efficiency_official.py:306-330) ----
  * lfsr_op_profile(1): from now on every instrumented operator entry point brackets its launches with a hipEvent pair on its launch stream (and any
  * earlier records are dropped); lfsr_op_profile(0): off (the default; a hook then costs one atomic load).  lfsr_op_profile_read waits for the recorded

@@ -115,6 +115,8 @@ SIGNATURES = {
     "lfsr_angconv_bwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
     "lfsr_epiconv_hv_bwd_workspace_floats": (c_sz, [c_i, c_i, c_i, c_i]),
     "lfsr_epiconv_hv_bwd": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "lfsr_set_arithmetic": (c_i, [c_i]),
+    "lfsr_get_arithmetic": (c_i, []),
     "lfsr_op_profile": (c_i, [c_i]),
     "lfsr_op_profile_read": (C.c_longlong, [C.c_char_p, c_sz]),
     "lfsr_distgssr_profile": (c_i, [c_p, c_i]),
@@ -172,6 +174,14 @@ def _elem(t):
     if eb not in (2, 4):
         raise LfsrError(f"unsupported element size {eb}")
     return eb
+
+
+ARITH_DEFAULT, ARITH_F32 = 0, 1
+
+
+def set_arithmetic(mode):
+    """lfsr_set_arithmetic: ARITH_DEFAULT (three exact bf16 terms on the bf16 MFMA pipe where a kernel has that form) or ARITH_F32 (every GEMM on fp32 MFMA); process-wide"""
+    check(load().lfsr_set_arithmetic(int(mode)), "set_arithmetic")
 
 
 def op_profile(enable):

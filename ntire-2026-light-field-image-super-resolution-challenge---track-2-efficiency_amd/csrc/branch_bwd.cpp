@@ -125,7 +125,7 @@ int lfsr_epi_branch_bwd_p2w(const float* dEh, const float* dEv, const float* xin
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
   // the two passes share EPIConv.0's weights: where the EPI-line kernel applies, ONE weight-gradient launch covers both (one slab per block instead of
   // two sets); else the gather form per pass
-  const char* wsel = getenv("LFSR_WGRAD_EPI");
+  const char* wsel = lfsr_sel("LFSR_WGRAD_EPI");
   const bool epi_merged = lfsr_wgrad_epi0_blocks(B, A, h, w, 2) > 0 && A == 5 && h <= 32 && w <= 32 && npix * 64 * 4 < (1LL << 31) && !(wsel && wsel[0] == 'g');
   int epi_slabs[2] = {0, 0};
   if (epi_merged) {

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512) void k_epi0_dgrad_lines(EpiDgradArgs p) {
 int lfsr_epi0_dgrad_launch(const float* dE, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, int vert, hipStream_t st) {
   LfsrOpTimer op_t("epi0_dgrad", B, h * w, st);
   if (!dE || !w_direct || !dx || B <= 0 || h <= 0 || w <= 0 || ((dx_stride | dx_choff) & 3)) return LFSR_E_ARG;
-  const char* sel = getenv("LFSR_DGRAD_EPI");
+  const char* sel = lfsr_sel("LFSR_DGRAD_EPI");
   if (A != 5 || (vert ? h : w) > 32 || (sel && sel[0] == 'g')) return LFSR_E_ARG;
   if ((long long)B * A * A * h * w * dx_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
   static std::atomic<bool> attr_set[64];
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_ang0_dgrad(const float* __restrict__ dA
 int lfsr_ang0_dgrad_launch(const float* dA16, const float* w_direct, float* dx, int dx_stride, int dx_choff, int B, int A, int h, int w, hipStream_t st) {
   LfsrOpTimer op_t("ang0_dgrad", B, h * w, st);
   if (!dA16 || !w_direct || !dx || B <= 0 || A <= 0 || h <= 0 || w <= 0 || ((dx_stride | dx_choff) & 3)) return LFSR_E_ARG;
-  const char* sel = getenv("LFSR_DGRAD_ANG");
+  const char* sel = lfsr_sel("LFSR_DGRAD_ANG");
   if (sel && sel[0] == 'g') return LFSR_E_ARG;
   const int AA = A * A, HW = h * w;
   int chunks = (HW + 255) / 256;            // >= 256 pixels per block
@@ -355,7 +355,7 @@ int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st) {
   p.M = g.M; p.N = g.N; p.Npad = npad32(g.N); p.A = g.A; p.AA = g.A * g.A; p.H = g.h; p.W = g.w; p.ntaps = g.ntaps; p.CH = g.CH; p.slope = 1.0f;
   if ((g.x_stride | g.x_choff) & 3) return LFSR_E_ARG;
   // fuse.0 dgrad (64 -> 144, masked by the saved concat buffer): the row-streaming kernel (LFSR_NO_ROWGEMM keeps the gather-GEMM: A/B runs)
-  if (g.in_mode == LFSR_IN_SAME && g.out_mode == LFSR_OUT_SAME && g.cin == 64 && g.N == 144 && g.ntaps == 1 && !g.R1 && g.M >= 2048 && !getenv("LFSR_NO_ROWGEMM") && !getenv("LFSR_DGRAD_PW")) {     // (LFSR_DGRAD_PW=gather: the gather-GEMM for this data gradient only -- the forward keeps its kernel)
+  if (g.in_mode == LFSR_IN_SAME && g.out_mode == LFSR_OUT_SAME && g.cin == 64 && g.N == 144 && g.ntaps == 1 && !g.R1 && g.M >= 2048 && !lfsr_sel("LFSR_NO_ROWGEMM") && !lfsr_sel("LFSR_DGRAD_PW")) {     // (LFSR_DGRAD_PW=gather: the gather-GEMM for this data gradient only -- the forward keeps its kernel)
     const int rc = lfsr_rowgemm_dgrad144_launch(g.X, g.x_stride, g.x_choff, g.Wp, g.Mk, g.mk_stride, g.mk_choff, g.mk_slope, g.Y, g.y_stride, g.y_choff, g.M, st);
     if (rc != LFSR_E_ARG) return rc;
   }

@@ -317,7 +317,7 @@ int lfsr_conv3x3_halo_launch(const float* x, int x_stride, int x_choff, const fl
   // persistent: one 141-KB-LDS block per CU walks tiles blockIdx.x, +grid, ... (uniform cost, no queue needed).  Tiles beyond
   // the last full round (L = ntiles % ncu) go to a second, channel-split launch when that halves the tail (2L <= ncu).
   int tail = (int)(nblk % ncu);
-  if (nblk < ncu || 2 * tail > ncu || getenv("LFSR_CONV_NOTAIL")) tail = 0;
+  if (nblk < ncu || 2 * tail > ncu || lfsr_sel("LFSR_CONV_NOTAIL")) tail = 0;
   const int body = (int)nblk - tail;
   if (body > 0) {
     p.tile_begin = 0; p.tile_count = body;

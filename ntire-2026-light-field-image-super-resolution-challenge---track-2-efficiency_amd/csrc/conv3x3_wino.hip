@@ -476,8 +476,8 @@ static int conv3_sel_mask(const char* sel) {
 }
 
 // LFSR_CONV3X3 selects the forward kernel; LFSR_DGRAD3 (same vocabulary) the data-gradient kernel, which otherwise follows LFSR_CONV3X3
-const char* lfsr_conv3_fwd_sel() { return getenv("LFSR_CONV3X3"); }
-const char* lfsr_conv3_dgrad_sel() { const char* d = getenv("LFSR_DGRAD3"); return d ? d : getenv("LFSR_CONV3X3"); }
+const char* lfsr_conv3_fwd_sel() { return lfsr_sel("LFSR_CONV3X3"); }
+const char* lfsr_conv3_dgrad_sel() { const char* d = lfsr_sel("LFSR_DGRAD3"); return d ? d : lfsr_sel("LFSR_CONV3X3"); }
 
 int lfsr_conv3_variant_mask() { return conv3_sel_mask(lfsr_conv3_fwd_sel()) | conv3_sel_mask(lfsr_conv3_dgrad_sel()); }
 
@@ -559,8 +559,8 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
   // tiles beyond the last full round (L = ntiles % CUs) go to a channel-split tail launch, two blocks per tile, when that halves
   // the tail (2L <= CUs); LFSR_CONV_TAIL=halo runs the tail on the direct 9-tap kernel instead (A/B)
   int tail = (int)(nblk % ncu);
-  if (nblk < ncu || 2 * tail > ncu || getenv("LFSR_CONV_NOTAIL")) tail = 0;
-  const char* tsel = getenv("LFSR_CONV_TAIL");
+  if (nblk < ncu || 2 * tail > ncu || lfsr_sel("LFSR_CONV_NOTAIL")) tail = 0;
+  const char* tsel = lfsr_sel("LFSR_CONV_TAIL");
   const bool tail_direct = tsel && tsel[0] == 'h' && w_direct;
   const int body = (int)nblk - tail;
   p.ntiles = body;

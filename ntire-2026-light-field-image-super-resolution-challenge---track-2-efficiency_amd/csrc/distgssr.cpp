@@ -518,7 +518,7 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   {
     // LFSR_BWD_OVERLAP: bit 0 = the 3x3 weight gradients beside their data gradients (measured negative, off); bit 1 = the small launches of the angular branch's
     // backward beside those of the epipolar branch, and EPIConv.0's weight gradient beside the read-modify-write chain of dx (default on: unset = "2")
-    const char* osel = getenv("LFSR_BWD_OVERLAP");
+    const char* osel = lfsr_sel("LFSR_BWD_OVERLAP");
     const int omode = osel ? atoi(osel) : 2;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (omode && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {

@@ -510,7 +510,8 @@ int lfsr_pack_epi_wino(const float* w1_direct_packed, float* out, hipStream_t st
 }
 
 bool lfsr_epi_use_b3() {
-  const char* esel = getenv("LFSR_EPI");
+  if (lfsr_arith_f32()) return false;
+  const char* esel = lfsr_sel("LFSR_EPI");
   return !(esel && (esel[0] == 'w' || esel[0] == 'd' || esel[0] == 'f' || esel[0] == 'g'));     // wino | direct | f32 | gather select an fp32-MFMA form
 }
 
@@ -557,11 +558,11 @@ int lfsr_epi_fused_launch(const float* x, int x_stride, int x_choff, const float
   if (grid <= 0) return LFSR_E_ARG;
   // item-major block order when both passes run and an item's lines fill whole tiles (LFSR_EPI_ORDER=pass keeps pass-major order: A/B runs)
   {
-    const char* osel = getenv("LFSR_EPI_ORDER");
+    const char* osel = lfsr_sel("LFSR_EPI_ORDER");
     if (which == 3 && (A * h) % LINES == 0 && (A * w) % LINES == 0 && !(osel && osel[0] == 'p')) { p.tpiH = A * h / LINES; p.tpiV = A * w / LINES; p.xcd_swz = (grid % 8 == 0) && !(osel && osel[0] == 'i'); }
   }
   // A = 5: stage 1 in Winograd F(2,5) form (the pack appended to the direct one by lfsr_pack_conv_weight); LFSR_EPI=direct keeps the direct form (A/B runs)
-  const char* esel = getenv("LFSR_EPI");
+  const char* esel = lfsr_sel("LFSR_EPI");
   p.W1u = w1_packed + 25 * 32 * 64;
   if (A == 5 && !(esel && esel[0] == 'd')) hipLaunchKernelGGL(k_epi_wino5, dim3((unsigned)grid), dim3(512), epi_wino_smem(), st, p);
   else if (A == 5) hipLaunchKernelGGL(k_epi_fused<5>, dim3((unsigned)grid), dim3(512), lfsr_epi_fused_smem(A), st, p);

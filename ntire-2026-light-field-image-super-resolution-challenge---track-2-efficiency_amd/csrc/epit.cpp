@@ -99,16 +99,16 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
   auto conv = [&](const float* in, const std::string& key, float* o, const float* r1, const float* r2, float slope) -> int {
     return lfsr_conv3x3_fwd(in, 64, 0, P.w(key), o, 64, 0, r1, 64, 0, r2, 64, 0, nimg, h, w, slope, stream);
   };
-  const char* lf = getenv("LFSR_LN_FUSE");
+  const char* lf = lfsr_sel("LFSR_LN_FUSE");
   // LayerNorms formed inside the consuming kernel: feed_forward.0 in the fused feed-forward (default: 293 us against 33 + 295 us, 10 launches less per forward);
   // the attention norm inside the q | k | v projection only with LFSR_LN_FUSE=2 -- measured SLOWER (334 us against 33 + 209 us: each of the four q | k column
   // panels repeats the norm of its row tile, and 384 x 128 fp32 weights do not fit one block's LDS); LFSR_LN_FUSE=0: every norm as its own launch
-  const char* rgs = getenv("LFSR_ROWGEMM");
-  const bool rowgemm_f32 = rgs && (rgs[0] == 'f' || rgs[0] == '1');
+  const char* rgs = lfsr_sel("LFSR_ROWGEMM");
+  const bool rowgemm_f32 = (rgs && (rgs[0] == 'f' || rgs[0] == '1')) || lfsr_arith_f32();
   // (late round 2) on the three-term bf16 row-GEMM with 128-column panels the fused attention norm DOES pay (818 -> 831 patches/s): default there; LFSR_LN_FUSE=1 keeps the LayerNorm launch
-  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf ? lf[0] == '2' : !rowgemm_f32, no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;
+  const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf ? lf[0] == '2' : !rowgemm_f32, no_ffn_fused = lfsr_sel("LFSR_NO_FFN_FUSED") != nullptr;
   // BasicTrans.forward (EPIT.py:110-128) over all sequences of one pass
-  const char* psel = getenv("LFSR_FFN_PRESPLIT");
+  const char* psel = lfsr_sel("LFSR_FFN_PRESPLIT");
   const bool presplit = !(psel && psel[0] == '0');      // LFSR_FFN_PRESPLIT=0: the kernel splits the weight chunks itself (A/B runs)
   auto trans = [&](const float* X, const std::string& e, int vertical, float* Yo, int blk) -> int {
     int r;
@@ -167,7 +167,7 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
     }
     cur = o;
   }
-  if ((c->s == 2 || c->s == 4) && !getenv("LFSR_NO_UPTAIL")) {
+  if ((c->s == 2 || c->s == 4) && !lfsr_sel("LFSR_NO_UPTAIL")) {
     RC(lfsr_up_tail_fwd(cur, 64, 0, P.w("upsampling.0.weight"), P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
   } else {
     RC(lfsr_upsample_ps_fwd(cur, 64, 0, P.w("upsampling.0.weight"), HR, B, A, h, w, c->s, stream));

@@ -241,8 +241,8 @@ int lfsr_ffn_ln_launch(const float* x, int x_stride, int x_choff, const float* l
   if (!x || !w1_packed || !w2_packed || !y || M <= 0 || H <= 0 || H % 32 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   if ((ln_g != nullptr) != (ln_b != nullptr)) return LFSR_E_ARG;
   {   // default: the three-term bf16 form (ffn_b3.hip); LFSR_FFN=f32 keeps this file's fp32-MFMA kernel (A/B runs)
-    const char* fsel = getenv("LFSR_FFN");
-    if (!(fsel && fsel[0] == 'f')) {
+    const char* fsel = lfsr_sel("LFSR_FFN");
+    if (!(fsel && fsel[0] == 'f') && !lfsr_arith_f32()) {
       const int rc = lfsr_ffn_b3_launch(x, x_stride, x_choff, ln_g, ln_b, ln_eps, w1_packed, w2_packed, res, res_stride, res_choff, y, y_stride, y_choff, M, K1, H, N2, slope, st, wsplit);
       if (rc != LFSR_E_ARG) return rc;
     }

@@ -242,7 +242,7 @@ int lfsr_pointwise_fwd(const float* x, int x_stride, int x_choff, int cin, const
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;
   p.M = M; p.N = N; p.Npad = npad32(N); p.A = 1; p.AA = 1; p.H = 1; p.W = 1; p.ntaps = 1; p.CH = N; p.slope = slope;
   hipStream_t st = lfsr_stream(stream);
-  if (M >= 2048 && !getenv("LFSR_NO_ROWGEMM")) {   // streaming kernel for the shapes it covers (fuse.0: 144 -> 64)
+  if (M >= 2048 && !lfsr_sel("LFSR_NO_ROWGEMM")) {   // streaming kernel for the shapes it covers (fuse.0: 144 -> 64)
     int rc = lfsr_rowgemm_launch(x, x_stride, x_choff, cin, w_packed, bias, nullptr, 0, 0, y, y_stride, y_choff, M, N, slope, st);
     if (rc != LFSR_E_ARG) return rc;
   }
@@ -263,7 +263,7 @@ int lfsr_angconv_fwd(const float* x, int x_stride, int x_choff, const float* w1_
   if (x_stride < x_choff + 64 || y_stride < y_choff + 16 || (x_stride | x_choff) & 3) return LFSR_E_ARG;
   hipStream_t st = lfsr_stream(stream);
   {
-    const char* sel = getenv("LFSR_ANG");   // LFSR_ANG=gather forces the two-launch gather-GEMM path (A/B runs)
+    const char* sel = lfsr_sel("LFSR_ANG");   // LFSR_ANG=gather forces the two-launch gather-GEMM path (A/B runs)
     if (!(sel && sel[0] == 'g') && lfsr_ang_fused_ok(A) && !((y_stride | y_choff) & 3))
       return lfsr_ang_fused_launch(x, x_stride, x_choff, w1_packed, w2_packed, tmp, y, y_stride, y_choff, B, A, h, w, slope, st);
   }
@@ -296,7 +296,7 @@ int lfsr_epiconv_gather(const float* x, int x_stride, int x_choff, const float* 
 }
 
 static bool epi_use_fused(int A, int h, int w) {
-  const char* sel = getenv("LFSR_EPI");   // LFSR_EPI=gather forces the two-launch gather-GEMM path (A/B runs)
+  const char* sel = lfsr_sel("LFSR_EPI");   // LFSR_EPI=gather forces the two-launch gather-GEMM path (A/B runs)
   return !(sel && sel[0] == 'g') && lfsr_epi_fused_ok(A, h, w);
 }
 

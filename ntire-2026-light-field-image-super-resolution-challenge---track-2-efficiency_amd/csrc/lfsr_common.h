@@ -13,6 +13,11 @@
   } while (0)
 
 static inline hipStream_t lfsr_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+// A/B ("lab") selectors: LFSR_* environment variables that pick an alternative kernel form of an operator for measurements and parity tests.  They are consulted
+// ONLY when the process runs with LFSR_LAB set (read once, at the first selector lookup): the product default is one tested path per operator and no getenv on the
+// launch path.  The one selection a product caller may make -- the arithmetic of the GEMMs that have an exact-three-term-bf16 form -- is an API: lfsr_set_arithmetic.
+const char* lfsr_sel(const char* name);
+bool lfsr_arith_f32();     // lfsr_set_arithmetic(LFSR_ARITH_F32): every GEMM on fp32 MFMA
 static inline unsigned lfsr_blocks(long long n, int per) {
   long long b = (n + per - 1) / per;
   return (unsigned)(b < 1 ? 1 : b);

@@ -126,14 +126,14 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
   RC(conv(C2, "conv_init.4.weight", BUF0, F0, L));                         // LFT.py:81
   RC(lfsr_lft_position_fwd(SPOS, APE, A, h, w, 64, stream));              // LFT.py:84-85
   const float* cur = BUF0;
-  const bool no_ffn_fused = getenv("LFSR_NO_FFN_FUSED") != nullptr;   // two-launch feed-forward (A/B runs)
-  const char* psel = getenv("LFSR_FFN_PRESPLIT");
+  const bool no_ffn_fused = lfsr_sel("LFSR_NO_FFN_FUSED") != nullptr;   // two-launch feed-forward (A/B runs)
+  const char* psel = lfsr_sel("LFSR_FFN_PRESPLIT");
   const bool presplit = !(psel && psel[0] == '0');                    // LFSR_FFN_PRESPLIT=0: the kernel splits the weight chunks itself (A/B runs)
-  const char* lf = getenv("LFSR_LN_FUSE");
+  const char* lf = lfsr_sel("LFSR_LN_FUSE");
   // LayerNorms formed inside the consuming kernel (see epit.cpp): feed_forward.0 inside the fused feed-forward by default; the attention norms inside the
   // q | k | v projection only with LFSR_LN_FUSE=2 (measured slower: 1464 against 143 + 795 us for SpaTrans at 32 patches); LFSR_LN_FUSE=0: all norms as launches
-  const char* rgs = getenv("LFSR_ROWGEMM");
-  const bool rowgemm_f32 = rgs && (rgs[0] == 'f' || rgs[0] == '1');
+  const char* rgs = lfsr_sel("LFSR_ROWGEMM");
+  const bool rowgemm_f32 = (rgs && (rgs[0] == 'f' || rgs[0] == '1')) || lfsr_arith_f32();
   // (late round 2) on the three-term bf16 row-GEMM with 128-column panels the fused attention norms DO pay (1636 -> 1680 patches/s): default there; LFSR_LN_FUSE=1 keeps the LayerNorm launches
   const bool ln_fuse = !(lf && lf[0] == '0'), ln_fuse_qkv = lf ? lf[0] == '2' : !rowgemm_f32;
   for (int b = 0; b < c->nlayer; ++b) {
@@ -202,7 +202,7 @@ int lfsr_lft_forward(lfsr_lft* c, const float* x, float* out, int B, int h, int 
     RC(lfsr_linear_fwd(T, 128, 0, 128, P.w(sp + "linear.0.weight"), nullptr, last ? BUF0 : nullptr, 64, 0, s_out, 64, 0, npix, 64, 1.0f, stream));
     cur = s_out;
   }
-  if ((c->s == 2 || c->s == 4) && !getenv("LFSR_NO_UPTAIL")) {
+  if ((c->s == 2 || c->s == 4) && !lfsr_sel("LFSR_NO_UPTAIL")) {
     RC(lfsr_up_tail_fwd(cur, 64, 0, P.w("upsampling.0.weight"), P.w("upsampling.3.weight"), x, out, B, A, h, w, c->s, L, stream));
   } else {
     RC(lfsr_upsample_ps_fwd(cur, 64, 0, P.w("upsampling.0.weight"), HR, B, A, h, w, c->s, stream));

@@ -263,8 +263,8 @@ int lfsr_rowgemm_ln_launch(const float* x, int x_stride, int x_choff, int K, con
   if (((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) return LFSR_E_ARG;
   if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
   {   // default: the three-term bf16 form (rowgemm_b3.hip); LFSR_ROWGEMM=f32 keeps the fp32-MFMA kernel below (bit-identical to LayerNorm launch + fp32 row-GEMM)
-    const char* rsel = getenv("LFSR_ROWGEMM");
-    if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1'))) {
+    const char* rsel = lfsr_sel("LFSR_ROWGEMM");
+    if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !lfsr_arith_f32()) {
       const int rc = lfsr_rowgemm_b3_ln_launch(x, x_stride, x_choff, K, w_packed, ln_g, ln_b, ln_eps, ln_cols, pe, pe_stride, pe_rows, pe_div, y, y_stride, y_choff,
                                                y2, y2_stride, y2_choff, split_n, M, N, st);
       if (rc != LFSR_E_ARG) return rc;
@@ -298,10 +298,10 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
   // x 64 columns -- X streamed once per 128 output columns, a B fragment feeding two MFMA column tiles.  Measured on EPIT (B = 8, two runs each in
   // one call, profiles/r02_logs/ab_bench_lines.json: bench11_epit*.json): 637-639 patches/s against 659-660 for the 64 x 64 form -- one block per CU hides less HBM latency
   // than two; the 64 x 64 form stays the default
-  const char* rsel = getenv("LFSR_ROWGEMM");
+  const char* rsel = lfsr_sel("LFSR_ROWGEMM");
   // the bias-free K = 64 / 128 linears (the transformers' projections) run on the bf16 MFMA pipe with their fp32 operands split EXACTLY into three bf16 terms
   // (rowgemm_b3.hip; error against fp64 below this file's fp32-MFMA kernel: tools/b3_accuracy.py); LFSR_ROWGEMM=f32 keeps the fp32-MFMA form (A/B runs), 128 its wide tiles
-  if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !bias && (K == 64 || K == 128 || K == 144)) {
+  if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !lfsr_arith_f32() && !bias && (K == 64 || K == 128 || K == 144)) {
     const int rc = lfsr_rowgemm_b3_launch(x, x_stride, x_choff, K, w_packed, res, res_stride, res_choff, y, y_stride, y_choff, M, N, slope, st);
     if (rc != LFSR_E_ARG) return rc;
   }

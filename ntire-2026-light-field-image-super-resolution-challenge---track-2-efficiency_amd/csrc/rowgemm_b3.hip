@@ -245,7 +245,7 @@ int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, con
   RowGemmB3Args p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = slope;
-  const char* nsel = getenv("LFSR_B3_NB");       // "128": 128-column panels where N allows (A/B runs: EPIT 818 -> 800, LFT 1636 -> 1646 patches/s; not the default)
+  const char* nsel = lfsr_sel("LFSR_B3_NB");       // "128": 128-column panels where N allows (A/B runs: EPIT 818 -> 800, LFT 1636 -> 1646 patches/s; not the default)
   const bool wide = nsel && nsel[0] == '1' && N % 128 == 0;
   switch (K) {
     case 64: return wide ? launch_b3<64, false, 128>(p, st) : launch_b3<64>(p, st);
@@ -269,7 +269,7 @@ int lfsr_rowgemm_b3_ln_launch(const float* x, int x_stride, int x_choff, int K, 
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.ln_cols = ln_cols; p.pe = pe; p.pe_stride = pe_stride; p.pe_rows = pe_rows; p.pe_div = pe_div;
   p.Y2 = y2; p.y2_stride = y2_stride; p.y2_choff = y2_choff; p.split_n = split_n;
   // 128-column panels by default here (the norm and the split are repeated per panel: EPIT 818 -> 831, LFT 1636 -> 1680 patches/s with them; LFSR_B3_NB=64: 64-column panels)
-  const char* nsel = getenv("LFSR_B3_NB");
+  const char* nsel = lfsr_sel("LFSR_B3_NB");
   const bool wide = !(nsel && nsel[0] == '6') && ln_cols % 128 == 0 && (!y2 || split_n % 128 == 0);
   switch (K) {
     case 64: return wide ? launch_b3<64, true, 128>(p, st) : launch_b3<64, true>(p, st);

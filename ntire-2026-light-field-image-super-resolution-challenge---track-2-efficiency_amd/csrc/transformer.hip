@@ -331,21 +331,21 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
   // EPI geometry (every angular position visible, <= 160 tokens per sequence, heads of 16): QK^T / softmax / PV on the matrix pipe
   // (attn_mfma.hip); LFSR_ATTN=valu keeps the VALU kernels below (A/B runs)
   {
-    const char* asel = getenv("LFSR_ATTN");
-    if (hd == 16 && !(asel && asel[0] == 'v') && !getenv("LFSR_ATTN_L1")) {
+    const char* asel = lfsr_sel("LFSR_ATTN");
+    if (hd == 16 && !(asel && asel[0] == 'v') && !lfsr_sel("LFSR_ATTN_L1")) {
       const int rc = lfsr_epi_attn_mfma_launch(q, q_stride, q_choff, k, k_stride, k_choff, v, v_stride, v_choff, o, o_stride, o_choff, nheads, ns0, ns1, ns2,
                                                bs0, bs1, bs2, n1, n2, st1, st2, l1, r1, l2, r2, clip2, lfsr_stream(stream));
       if (rc != LFSR_E_ARG) return rc;
     }
     // 5 x 5 spatial windows (LFT's SpaTrans): tiles of 4 x 4 queries against the 8 x 8 keys around them on the matrix pipe (win_attn_mfma.hip)
-    if (hd == 16 && !(asel && asel[0] == 'v') && !getenv("LFSR_ATTN_L1")) {
+    if (hd == 16 && !(asel && asel[0] == 'v') && !lfsr_sel("LFSR_ATTN_L1")) {
       const int rc = lfsr_win_attn_mfma_launch(q, q_stride, q_choff, k, k_stride, k_choff, v, v_stride, v_choff, o, o_stride, o_choff, nheads, ns0, ns1, ns2,
                                                bs0, bs1, bs2, n1, n2, st1, st2, l1, r1, l2, r2, clip2, lfsr_stream(stream));
       if (rc != LFSR_E_ARG) return rc;
     }
   }
   // LDS-tiled path (hd 16, heads in pairs): stage the keys a tile of queries can see once; used when the staged tile fits
-  if (hd == 16 && nheads % 2 == 0 && !getenv("LFSR_ATTN_L1")) {
+  if (hd == 16 && nheads % 2 == 0 && !lfsr_sel("LFSR_ATTN_L1")) {
     constexpr int HB = 2, TS = HB * 32 + 4;
     int T1 = n1;                                            // whole sequence if it fits (EPIT: 5 x 32 tokens)
     auto smem_for = [&](int t1) { int rows = t1 + l1 + r1 - 1; if (rows > n1) rows = n1; return (size_t)rows * n2 * TS * 4; };
@@ -370,8 +370,8 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
   }
   // heads of 8, all eight in one block, whole (short) sequences: LFT's angular attention (25 views per pixel).  One block per sequence stages its 25 x (k | v) rows
   // once; the L1-served kernel below re-reads them for every query (it ran at the L1's 64 B/clk: 0.43 ms per launch at 32 patches).  LFSR_ATTN_ANG=l1 keeps it (A/B runs)
-  if (hd == 8 && nheads == 8 && n2 == 1 && l1 >= n1 && r1 >= n1 && n1 <= 64 && !getenv("LFSR_ATTN_L1")) {
-    const char* asel = getenv("LFSR_ATTN_ANG");
+  if (hd == 8 && nheads == 8 && n2 == 1 && l1 >= n1 && r1 >= n1 && n1 <= 64 && !lfsr_sel("LFSR_ATTN_L1")) {
+    const char* asel = lfsr_sel("LFSR_ATTN_ANG");
     if (!(asel && asel[0] == 'l' && asel[1] == '1')) {
       constexpr int TS8 = 8 * 20 + 4;
       const size_t smem = (size_t)n1 * TS8 * 4;
@@ -399,7 +399,7 @@ int lfsr_linear_fwd(const float* x, int x_stride, int x_choff, int cin, const fl
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
   p.M = (int)M; p.N = N; p.Npad = npad32(N); p.A = 1; p.AA = 1; p.H = 1; p.W = 1; p.ntaps = 1; p.CH = N; p.slope = slope;
   hipStream_t st = lfsr_stream(stream);
-  if (M >= 2048 && !getenv("LFSR_NO_ROWGEMM")) {
+  if (M >= 2048 && !lfsr_sel("LFSR_NO_ROWGEMM")) {
     int rc = lfsr_rowgemm_launch(x, x_stride, x_choff, cin, w_packed, bias, res, res_stride, res_choff, y, y_stride, y_choff, M, N, slope, st);
     if (rc != LFSR_E_ARG) return rc;
   }

@@ -572,8 +572,8 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
   p.tiles_y = (A * h + UT_Y - 1) / UT_Y; p.tiles_x = (A * w + UT_X - 1) / UT_X;
   long long grid = (long long)B * p.tiles_y * p.tiles_x;
   if (grid > 0x7fffffffLL) return LFSR_E_ARG;
-  const char* usel = getenv("LFSR_UPTAIL");         // "v1" / "v2": the first / second (fp32-MFMA) forms (A/B runs)
-  if (!(usel && usel[0] == 'v')) {
+  const char* usel = lfsr_sel("LFSR_UPTAIL");         // "v1" / "v2": the first / second (fp32-MFMA) forms (A/B runs)
+  if (!(usel && usel[0] == 'v') && !lfsr_arith_f32()) {
     const int smem3 = (UT2_ROWS * LDS_ROW + 64 * 9) * 4 + 2 * 3 * 64 * 64 * 2;
     static std::atomic<bool> attr3_set[64];
     if (!attr3_set[dev]) {
@@ -588,7 +588,7 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
     LFSR_CHECK_LAUNCH();
     return LFSR_OK;
   }
-  if (!(usel[1] == '1')) {
+  if (!(usel && usel[1] == '1')) {
     const int smem2 = (2 * UT2_ROWS * LDS_ROW + 2 * 64 * LDS_ROW + 64 * 9) * 4;
     static std::atomic<bool> attr2_set[64];
     if (!attr2_set[dev]) {

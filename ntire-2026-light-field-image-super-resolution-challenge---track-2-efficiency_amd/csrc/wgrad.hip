@@ -672,7 +672,7 @@ int lfsr_wgrad_launch(int gmode, int xmode, const float* G, int g_stride, int g_
 
 
 // LFSR_WGRAD3=direct keeps the direct-form kernel (A/B runs); the Winograd form is the default
-static bool wgrad3_wino() { const char* s = getenv("LFSR_WGRAD3"); return !(s && s[0] == 'd'); }
+static bool wgrad3_wino() { const char* s = lfsr_sel("LFSR_WGRAD3"); return !(s && s[0] == 'd'); }
 
 int lfsr_wgrad_conv3_blocks(int n_img, int h, int w) {
   const int tr = wgrad3_wino() ? 2 : WT_R;
@@ -756,7 +756,7 @@ int lfsr_wgrad_epi0_blocks(int B, int A, int h, int w, int vert) {
 int lfsr_wgrad_epi0_launch(const float* dE, const float* dE_v, const float* X, int x_stride, int x_choff, float* P, int B, int A, int h, int w, int vert, hipStream_t st) {
   LfsrOpTimer op_t("epi0_wgrad", B, h * w, st);
   if (!dE || !X || !P || B <= 0 || h <= 0 || w <= 0 || ((x_stride | x_choff) & 3) || vert < 0 || vert > 2 || (vert == 2 && !dE_v)) return LFSR_E_ARG;
-  const char* sel = getenv("LFSR_WGRAD_EPI");
+  const char* sel = lfsr_sel("LFSR_WGRAD_EPI");
   if (A != 5 || (vert != 0 && h > 32) || (vert != 1 && w > 32) || (sel && sel[0] == 'g')) return LFSR_E_ARG;
   if ((long long)B * A * A * h * w * x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
   static std::atomic<bool> attr_set[64];
@@ -787,7 +787,7 @@ int lfsr_wgrad_pw144_blocks(int M) {
 int lfsr_wgrad_pw144_launch(const float* G, int g_stride, int g_choff, const float* X, int x_stride, int x_choff, float* P, int M, hipStream_t st) {
   LfsrOpTimer op_t("pw144_wgrad", M, 0, st);
   if (!G || !X || !P || M <= 0 || ((g_stride | g_choff | x_stride | x_choff) & 3) || g_stride < g_choff + 64 || x_stride < x_choff + 144) return LFSR_E_ARG;
-  const char* sel = getenv("LFSR_WGRAD_PW");
+  const char* sel = lfsr_sel("LFSR_WGRAD_PW");
   if (sel && sel[0] == 'g') return LFSR_E_ARG;
   static std::atomic<bool> attr_set[64];
   int dev = 0;

@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("LFSR_LAB", "1")   # the library's A/B selectors (LFSR_* environment variables) are live only in a process started with LFSR_LAB set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

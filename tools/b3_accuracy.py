@@ -1,5 +1,6 @@
 """Error against fp64 of the fp32-MFMA row-GEMM and of the three-term bf16 form (the default; LFSR_ROWGEMM=f32 selects the fp32-MFMA kernel) on the same data."""
 import os, sys
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lfsr_amd import capi

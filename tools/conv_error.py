@@ -2,6 +2,7 @@
 """Round-off of the HIP DistgSSR forward against the fp64 oracle's golden output, for the Winograd (default) and the direct
 (LFSR_CONV3X3=halo) form of the 3x3 convs.  usage: python tools/conv_error.py"""
 import os, sys
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,6 +3,7 @@
 Usage: python tools/conv_micro.py [lib.so]   (env LFSR_CONV_DBG / LFSR_CONV3X3 select diagnostic variants)"""
 import ctypes as C
 import os
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import sys
 import torch
 

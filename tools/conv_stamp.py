@@ -2,6 +2,7 @@
 """Diagnostic: where a persistent conv3x3 block spends its cycles (wave 0's s_memtime deltas per segment).
 Needs a library built with -DLFSR_CONV_DIAG; usage: python tools/conv_stamp.py lib.so"""
 import os, sys
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lfsr_amd import capi

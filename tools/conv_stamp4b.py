@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: cycles per segment of the split-bf16 F(4x4) conv kernel (s_memtime deltas of every consumer and producer wave).  Needs a
 library built with -DLFSR_CONV_DIAG (tools/build_w4b_var.sh "diag:-DLFSR_CONV_DIAG"); usage: python tools/conv_stamp4b.py lib.so"""
+import os as _os
+_os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: cycles per phase of the symmetric-wave F(4x4) conv kernel (wave 0's s_memtime deltas).  Needs a library built with
 -DLFSR_CONV_DIAG; usage: LFSR_CONV3X3=wino4s python tools/conv_stamp4s.py lib.so"""
+import os as _os
+_os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import ctypes, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,6 +3,7 @@
 with and without a residual operand, and prints the max difference against the direct kernel.
 usage: python tools/conv_time.py [n_img] [reps]"""
 import os, sys
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lfsr_amd import capi

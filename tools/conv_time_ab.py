@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import torch
 sys.path.insert(0, "/root/repo")
 from lfsr_amd import capi

@@ -1,5 +1,6 @@
 """time of both EPI passes (lfsr_epiconv_hv_fwd) at the bench geometry (B = 32, 5x5 views of 32x32); LFSR_HIP_LIB selects an ablation build (tools/build_abl.sh)"""
 import os, sys
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lfsr_amd import capi

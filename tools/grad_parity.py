@@ -19,6 +19,7 @@ import time
 import numpy as np
 import torch
 
+os.environ.setdefault("LFSR_LAB", "1")     # this tool drives the library's A/B selectors
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lfsr_amd import capi                                   # noqa: E402

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LFSR_LAB=1   # (A/B selectors of the library are live only under LFSR_LAB)
 # round 2, final evidence: bench lines of the four workloads, rocprofv3 kernel-trace stats of each, FETCH_SIZE / WRITE_SIZE passes of the headline
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out/r2/final; mkdir -p $O; rm -rf $O/prof_* $O/pmc_*

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LFSR_LAB=1   # (A/B selectors of the library are live only under LFSR_LAB)
 # round 3, call 3: EPI branch on the three-term bf16 pipe: operator tests, accuracy sweep, whole-model tests, A/B bench in one process environment
 set -e
 mkdir -p gpurun_out/r3

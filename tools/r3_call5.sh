@@ -1,4 +1,5 @@
 #!/bin/bash
+export LFSR_LAB=1   # (A/B selectors of the library are live only under LFSR_LAB)
 # round 3, call 5: software-pipelined split in k_epi_b3; batched staging in k_win_attn_mfma
 set -e
 mkdir -p gpurun_out/r3

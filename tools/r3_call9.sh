@@ -1,4 +1,5 @@
 #!/bin/bash
+export LFSR_LAB=1   # (A/B selectors of the library are live only under LFSR_LAB)
 # round 3, call 9: k_epi_b3 with phase-shifted split bursts and a leaner tail
 set -e
 mkdir -p gpurun_out/r3

@@ -6,7 +6,7 @@ O=$R/gpurun_out/r3/final; mkdir -p $O; rm -rf $O/prof_* $O/pmc_*
 cd $R
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
 for wl in epit lft train; do timeout -k 10 300 python bench.py --workload $wl > $O/bench_$wl.json 2> $O/bench_$wl.err || exit 1; done
-for wl in epit lft; do LFSR_ROWGEMM=f32 LFSR_FFN=f32 LFSR_UPTAIL=v2 timeout -k 10 300 python bench.py --workload $wl > $O/bench_${wl}_f32.json 2> $O/bench_${wl}_f32.err || exit 1; done
+for wl in epit lft; do timeout -k 10 300 python bench.py --workload $wl --arithmetic f32 > $O/bench_${wl}_f32.json 2> $O/bench_${wl}_f32.err || exit 1; done
 python - <<'PY'
 import json
 for n in ("bench", "bench_epit", "bench_lft", "bench_train", "bench_epit_f32", "bench_lft_f32"):

@@ -1,5 +1,6 @@
 """wino4b (split-bf16 F(4x4,3x3)) against wino4 and the fp64 direct form; timing at the bench geometry."""
 import os, sys, time
+os.environ.setdefault("LFSR_LAB", "1")   # (this tool drives the library's A/B selectors, live only under LFSR_LAB)
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from lfsr_amd import capi
