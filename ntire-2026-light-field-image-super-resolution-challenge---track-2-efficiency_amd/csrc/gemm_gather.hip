@@ -53,14 +53,18 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
 // 16 threads per output pixel, 4 output channels each -> one 256-B coalesced store per pixel.
 __global__ __launch_bounds__(256) void k_initconv(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int y_stride, int y_choff,
                                                   int B, int A, int h, int wd) {
-  __shared__ float sw[64 * 9];
-  for (int i = threadIdx.x; i < 64 * 9; i += 256) sw[i] = w[i];
-  __syncthreads();
   const long long npix = (long long)B * A * A * h * wd;
   const int Wm = A * wd, Hm = A * h;
+  // a thread keeps ITS four channels for every pixel it visits (the grid stride is a multiple of 16), so their 36 weights live in registers: no LDS read per FMA
+  // (round 3: 75 -> see DESIGN; the first form re-read the weights from LDS for every pixel)
+  const int c4 = (int)(threadIdx.x & 15) * 4;
+  float wr[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[i][k] = w[(c4 + i) * 9 + k];
   for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < npix * 16; g += (long long)gridDim.x * 256) {
     long long pix = g >> 4;
-    int c4 = (int)(g & 15) * 4;
     int xx = (int)(pix % wd);
     long long t = pix / wd;
     int yy = (int)(t % h);
@@ -69,19 +73,22 @@ __global__ __launch_bounds__(256) void k_initconv(const float* __restrict__ x, c
     int b = (int)(t / (A * A));
     int u = view / A, v = view - u * A;
     const float* img = x + (long long)b * Hm * Wm + (long long)(u * h) * Wm + v * wd;  // this view's top-left in the mosaic
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float xv[9];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         int sy = yy + ky - 1, sx = xx + kx - 1;
-        float xv = (sy >= 0 && sy < h && sx >= 0 && sx < wd) ? img[(long long)sy * Wm + sx] : 0.f;
-        int k = ky * 3 + kx;
-        a0 = fmaf(xv, sw[(c4 + 0) * 9 + k], a0);
-        a1 = fmaf(xv, sw[(c4 + 1) * 9 + k], a1);
-        a2 = fmaf(xv, sw[(c4 + 2) * 9 + k], a2);
-        a3 = fmaf(xv, sw[(c4 + 3) * 9 + k], a3);
+        xv[ky * 3 + kx] = (sy >= 0 && sy < h && sx >= 0 && sx < wd) ? img[(long long)sy * Wm + sx] : 0.f;
       }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      a0 = fmaf(xv[k], wr[0][k], a0);
+      a1 = fmaf(xv[k], wr[1][k], a1);
+      a2 = fmaf(xv[k], wr[2][k], a2);
+      a3 = fmaf(xv[k], wr[3][k], a3);
+    }
     *reinterpret_cast<float4*>(y + pix * y_stride + y_choff + c4) = make_float4(a0, a1, a2, a3);
   }
 }

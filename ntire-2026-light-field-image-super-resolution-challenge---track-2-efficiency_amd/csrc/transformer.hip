@@ -62,6 +62,7 @@ struct AttnArgs {
   float scale;
   float scale2;                                 // scale * log2(e): the LDS-tiled kernels run their softmax in base 2
   long long total;                              // nseq * n1 * n2 * nheads
+  int loop_stage;                               // 1: the LDS-tiled kernel stages its keys with the plain loop (A/B: LFSR_ATTN_ANG=loop)
 };
 
 template <int HD>
@@ -148,6 +149,32 @@ __global__ __launch_bounds__(1024) void k_window_attn_lds(AttnArgs p, int T1, in
   // stage K | V : one 16-B chunk per thread-iteration; chunk c of a (key, head): c < HD/4 -> K, else V.  (Issuing four loads before their four LDS stores was
   // measured: 940 -> 1166 us for LFT's spatial attention -- the plain loop is already pipelined by the compiler)
   constexpr int CPT = 2 * HD / 4;                     // chunks per (key, head)
+  if (HD == 8 && !p.loop_stage && nkey * HB * CPT <= 4 * (int)blockDim.x) {
+    // short sequences (LFT's angular attention: 25 keys x 8 heads x 4 chunks = 800 items for 256 threads): all of a thread's loads before its first LDS store --
+    // as a plain loop the four items of a thread are four serial memory round trips, most of this small block's life (round 3)
+    float4 sv[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = threadIdx.x + it * blockDim.x;
+      sv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < nkey * HB * CPT) {
+        int c = i % CPT, r = i / CPT, h = r % HB, key = r / HB;
+        int k1 = k_lo + key / p.n2, k2 = key % p.n2;
+        long long pix = base + k1 * p.st1 + k2 * p.st2;
+        const float* src = c < HD / 4 ? p.K + pix * p.k_stride + p.k_choff + (hb + h) * HD + c * 4
+                                      : p.V + pix * p.v_stride + p.v_choff + (hb + h) * HD + (c - HD / 4) * 4;
+        sv[it] = *reinterpret_cast<const float4*>(src);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = threadIdx.x + it * blockDim.x;
+      if (i < nkey * HB * CPT) {
+        int c = i % CPT, r = i / CPT, h = r % HB, key = r / HB;
+        *reinterpret_cast<float4*>(skv + key * TS + h * HS + c * 4) = sv[it];
+      }
+    }
+  } else
   for (int i = threadIdx.x; i < nkey * HB * CPT; i += blockDim.x) {
     int c = i % CPT, r = i / CPT, h = r % HB, key = r / HB;
     int k1 = k_lo + key / p.n2, k2 = key % p.n2;
@@ -373,6 +400,7 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
   if (hd == 8 && nheads == 8 && n2 == 1 && l1 >= n1 && r1 >= n1 && n1 <= 64 && !lfsr_sel("LFSR_ATTN_L1")) {
     const char* asel = lfsr_sel("LFSR_ATTN_ANG");
     if (!(asel && asel[0] == 'l' && asel[1] == '1')) {
+      p.loop_stage = asel && asel[0] == 'l' && asel[1] == 'o';
       constexpr int TS8 = 8 * 20 + 4;
       const size_t smem = (size_t)n1 * TS8 * 4;
       int threads = (n1 * 8 + 63) / 64 * 64;
