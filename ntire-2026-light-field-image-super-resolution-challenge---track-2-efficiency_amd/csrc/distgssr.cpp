@@ -39,7 +39,7 @@ struct lfsr_distgssr {
   size_t table_cap = 0;
   // backward: the weight gradient of a 3x3 layer runs on a side stream beside the layer's data gradient (both read the same dY); created on first use
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_w = nullptr, ev_red[2] = {nullptr, nullptr};
   bool profiling = false;
   struct Ev { int cls; hipEvent_t a, b; };
   bool profile_all = true;
@@ -115,6 +115,8 @@ void lfsr_distgssr_destroy(lfsr_distgssr* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->ev_w) (void)hipEventDestroy(c->ev_w);
+  for (int i = 0; i < 2; ++i) if (c->ev_red[i]) (void)hipEventDestroy(c->ev_red[i]);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
@@ -361,7 +363,7 @@ struct TrainWs {
   float *F0, *D;
   std::vector<float*> S1, CAT, A16, EH, EV, FZ, OUT, GOUT;
   // backward scratch
-  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *dE32V, *G16, *XG9, *P[4], *PA, *small;   // PA: partial slabs of the angular branch (its own: it may run beside the epipolar one)
+  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *dE32V, *G16, *XG9, *P[4], *PA, *PW[2], *small;   // PA: partial slabs of the angular branch (its own: it may run beside the epipolar one)
   size_t pfloats;
   size_t total;
 };
@@ -402,6 +404,7 @@ void train_layout(const lfsr_distgssr* c, int B, int h, int w, float* base, Trai
   t.pfloats = max_partial_floats(c, B, h, w);
   for (int i = 0; i < 4; ++i) t.P[i] = take(t.pfloats);
   t.PA = take(lfsr_branch_bwd_partial_floats(B, c->A, h, w));
+  for (int i = 0; i < 2; ++i) t.PW[i] = take((size_t)256 * 9 * 64 * 64);   // the 3x3 weight gradients' slabs, alternating: the reduce of one runs beside the next op
   t.small = take(64 * 1024);
   t.total = o;
 }
@@ -514,7 +517,7 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   // gradient's blocks could fill them.  MEASURED NEGATIVE (round 3, two runs each in one call, profiles/r03_logs/c6_overlap.txt): 25.3 ms with the side stream against
   // 24.5 ms on one stream -- both kernels are persistent one-block-per-CU grids (159 KB / 115 KB of LDS: never co-resident on a CU), so interleaving their blocks only
   // lengthens both.  Kept as an option: LFSR_BWD_OVERLAP=1.  Every wgrad3 is followed by its dgrad3 below.  Not under stream capture.
-  bool overlap = false, overlap_br = false, overlap_pw = false;
+  bool overlap = false, overlap_br = false, overlap_pw = false, overlap_red = false;
   {
     // LFSR_BWD_OVERLAP: bit 0 = the 3x3 weight gradients beside their data gradients (measured negative, off); bit 1 = the small launches of the angular branch's
     // backward beside those of the epipolar branch, and EPIConv.0's weight gradient beside the read-modify-write chain of dx (default on: unset = "2")
@@ -526,20 +529,38 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_red[0], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_red[1], hipEventDisableTiming) == hipSuccess;
         if (!ok) { if (c->side) (void)hipStreamDestroy(c->side); c->side = nullptr; }
       }
       overlap = c->side != nullptr && (omode & 1);
       overlap_br = c->side != nullptr && (omode & 2);
       overlap_pw = c->side != nullptr && (omode & 4);      // fuse.0's weight gradient beside its data gradient (A/B)
+      overlap_red = c->side != nullptr && (omode & 8) && !overlap;   // the slab reduce of a 3x3 weight gradient on the side stream, beside the data gradient that follows
     }
   }
   bool forked = false;
+  int nred = 0;
   // weight gradient of a 3x3 conv: dW[tap][n][k] = sum_m g[m][n] * xin[conv3 src(m,tap)][k]
   auto wgrad3 = [&](const std::string& key, const float* xin, const float* g, int g_stride) -> int {
     hipStream_t ws = st;
     if (overlap) {
       if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return LFSR_E_ARG;
       ws = c->side; forked = true;
+    }
+    if (overlap_red) {
+      // the weight gradient itself stays on the caller's stream; its 11-us slab reduce (37.7 MB of partials, no LDS, small blocks) goes to the side stream, where it
+      // runs beside the persistent data-gradient kernel that follows.  Two slab buffers alternate: before a buffer is written again the caller's stream waits for the
+      // reduce that read it two weight gradients ago.
+      const int b = nred & 1;
+      if (nred >= 2 && hipStreamWaitEvent(st, c->ev_red[b], 0) != hipSuccess) return LFSR_E_ARG;
+      int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.PW[b], nimg, h, w, st);
+      if (r) return r;
+      if (hipEventRecord(c->ev_w, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_w, 0) != hipSuccess) return LFSR_E_ARG;
+      r = lfsr_wgrad_reduce(t.PW[b], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, c->side);
+      if (hipEventRecord(c->ev_red[b], c->side) != hipSuccess) return LFSR_E_ARG;
+      ++nred;
+      return r;
     }
     int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.P[0], nimg, h, w, ws);
     if (!r) r = lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, ws);
@@ -663,6 +684,9 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   RC(lfsr_init_gather9(x, t.XG9, B, A, h, w, st));
   RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, gcur, 64, 0, t.XG9, 16, 0, t.P[0], npix, 64, 16, 1, h, w, 1, st));
   RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 1, 16), nullptr, 0, G("init_conv.weight"), 64, 16, 1, 0, 0, 0, 9, 0, st));
+  if (overlap_red)      // the caller's stream owns the gradient bucket again only after the last side-stream reduces
+    for (int b = 0; b < 2 && b < nred; ++b)
+      if (hipStreamWaitEvent(st, c->ev_red[b], 0) != hipSuccess) return LFSR_E_ARG;
 #undef RC
   return LFSR_OK;
 }
