@@ -122,8 +122,18 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
 
   // ---- group geometry (block-uniform) and this wave's line ----
   struct Line { int vert, base, len, vstride, pstride, choff; long long rowbase; int rowstep; };
-  auto line_of = [&](int grp) -> Line {
+  // Work units of a block: whole groups of 8 lines in its full rounds (group vb + i nb); the groups LEFT OVER after the last full round (B = 8: 320 groups on 256 CUs)
+  // are cut into f = 2 or 4 sub-groups of 8 / f lines while they still fit one round, so the last round costs a wave its one line with a SIMD to itself instead of
+  // a whole group time on a quarter of the chip.  Per-line arithmetic is untouched (same bits).
+  const int nfr = ngroups / nb, nfull = nfr * nb, rem = ngroups - nfull;
+  const int fsub = rem == 0 ? 1 : (rem * 4 <= nb ? 4 : rem * 2 <= nb ? 2 : 1);
+  const int nunits = nfr + (vb < rem * fsub ? 1 : 0);                 // (block-uniform)
+  auto line_of = [&](int it) -> Line {
     Line L;
+    int grp, l0 = 0, nl = EB_LINES;
+    if (it < nfr) grp = vb + it * nb;
+    else if (it < nunits) { grp = nfull + vb / fsub; nl = EB_LINES / fsub; l0 = (vb % fsub) * nl; }
+    else grp = ngroups;                                                 // past the end: an absent line, every access out of range
     int tile;
     if (p.tpiH > 0) {
       const int per = p.tpiH + p.tpiV, item = grp / per, r = grp - item * per;
@@ -139,9 +149,9 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
     L.vstride = L.vert ? A * HW : HW;
     L.pstride = L.vert ? p.W : 1;
     L.choff = L.vert ? p.choffV : p.choffH;
-    const int ln = tile * EB_LINES + wave;
+    const int ln = tile * EB_LINES + l0 + wave;
     L.base = -1; L.rowbase = 0; L.rowstep = 0;
-    if (grp < ngroups && ln < nlines) {
+    if (grp < ngroups && wave < nl && ln < nlines) {
       const int q = ln / across, o = ln - q * across;     // horizontal: q = b*A+u, o = y;  vertical: q = b*A+v, o = x
       if (!L.vert) L.base = q * A * HW + o * p.W;
       else { const int b = q / A, v = q - b * A; L.base = (b * A * A + v) * HW + o; }
@@ -187,9 +197,9 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
     }
   };
 
-  int grp = vb;
-  if (grp >= ngroups) return;           // (block-uniform: before any barrier)
-  Line L = line_of(grp);
+  int it = 0;
+  if (nunits == 0) return;              // (block-uniform: before any barrier)
+  Line L = line_of(0);
   load_x(L, 0, rawA);
   load_x(L, 1, rawB);
   load_w(0);
@@ -211,9 +221,8 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
   const unsigned char* const w2b = sW2 + (g * 160 + l15) * 16;
 
   for (;;) {
-    const int ngrp = grp + nb;
-    const bool more = ngrp < ngroups;   // (block-uniform)
-    const Line Ln = line_of(more ? ngrp : ngroups);     // (ngroups: an absent line, every access out of range)
+    const bool more = it + 1 < nunits;  // (block-uniform)
+    const Line Ln = line_of(it + 1);    // (past the end: an absent line, every access out of range)
     f32x4e acc[5][2][2];
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx)
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
       for (int dx = 0; dx < 5; ++dx) sacc += acc[dx][0][1] + acc[dx][1][0] + acc[dx][1][1] + acc[dx][0][0];
       if (L.base >= 0 && l15 < L.len) *reinterpret_cast<f32x4e*>(p.Y + (long long)(L.base + l15 * L.pstride) * p.y_stride + L.choff + 4 * g) = sacc;
       if (!more) break;
-      grp = ngrp; L = Ln;
+      ++it; L = Ln;
       continue;
     }
     f32x4e tv[2][2];                    // [mt][nt]: channels 16 mt + 4 g .. + 3 of position 16 nt + l15
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512) void k_epi_b3(EpiB3Args p) {
         }
     }
     if (!more) break;
-    grp = ngrp;
+    ++it;
     L = Ln;
   }
 }

@@ -136,3 +136,24 @@ def test_epi_branch_three_term_vs_fp32_kernel(B, h, w, monkeypatch):
     assert eb.max() < 1e-4
     assert eb.mean() <= 1.1 * ef.mean() and eb.max() <= 1.5 * ef.max()
     assert not np.array_equal(bh, fh)            # the two selections really ran different kernels
+
+
+def test_epi_branch_batch8_equals_smaller_batches():
+    """B = 8 at angRes 5, 32x32 (320 groups of 8 EPI lines on 256 CUs: the persistent kernel's leftover groups are cut into 2-line sub-groups) against the same items run
+    in batches of 2 and 3 (whole groups only): bit-equal -- the unit decomposition changes no line's arithmetic"""
+    A, h, w, B = 5, 32, 32, 8
+    g = torch.Generator().manual_seed(88)
+    x = torch.randn(B, 64, A * h, A * w, generator=g)
+    w1p = capi.pack_conv_weight((torch.randn(32, 64, 1, A * A, generator=g) * 0.03).cuda())
+    w2p = capi.pack_conv_weight((torch.randn(A * 32, 32, 1, 1, generator=g) * 0.15).cuda())
+
+    def run(xb):
+        Bb = xb.shape[0]
+        xv = capi.nchw_to_vcl(xb.cuda().contiguous(), A, 1)
+        out = torch.full((xv.shape[0], 64), float("nan"), device="cuda")
+        capi.epiconv_hv(xv, w1p, w2p, Bb, A, h, w, 0.1, out, 0, 32)
+        return out.reshape(Bb, -1)
+    full = run(x)
+    assert torch.isfinite(full).all()
+    parts = torch.cat([run(x[0:2]), run(x[2:5]), run(x[5:8])], 0)
+    assert torch.equal(full, parts)
