@@ -55,15 +55,8 @@ __device__ __forceinline__ float eb_residual(float a) { return a - __uint_as_flo
 // eight consecutive floats -> their three bf16 planes in MFMA operand order
 __device__ __forceinline__ void eb_split8(const f32x4e lo, const f32x4e hi, u32x4e& p0, u32x4e& p1, u32x4e& p2) {
   const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  float r[8], q[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { r[j] = eb_residual(a[j]); q[j] = eb_residual(r[j]); }
-  p0 = u32x4e{eb_hi_pair(__float_as_uint(a[1]), __float_as_uint(a[0])), eb_hi_pair(__float_as_uint(a[3]), __float_as_uint(a[2])),
-              eb_hi_pair(__float_as_uint(a[5]), __float_as_uint(a[4])), eb_hi_pair(__float_as_uint(a[7]), __float_as_uint(a[6]))};
-  p1 = u32x4e{eb_hi_pair(__float_as_uint(r[1]), __float_as_uint(r[0])), eb_hi_pair(__float_as_uint(r[3]), __float_as_uint(r[2])),
-              eb_hi_pair(__float_as_uint(r[5]), __float_as_uint(r[4])), eb_hi_pair(__float_as_uint(r[7]), __float_as_uint(r[6]))};
-  p2 = u32x4e{eb_hi_pair(__float_as_uint(q[1]), __float_as_uint(q[0])), eb_hi_pair(__float_as_uint(q[3]), __float_as_uint(q[2])),
-              eb_hi_pair(__float_as_uint(q[5]), __float_as_uint(q[4])), eb_hi_pair(__float_as_uint(q[7]), __float_as_uint(q[6]))};
+  for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
 
 // asm MFMA with the accumulator tied (conv3x3_wino4b.hip: the builtin's register allocation may overlap vDst with a source partially)

@@ -33,15 +33,8 @@ struct FfnB3Args {
 __device__ __forceinline__ unsigned c3_hi_pair(unsigned hi_src, unsigned lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
 __device__ __forceinline__ float c3_residual(float a) { return a - __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ void c3_split8(const float a[8], u32x4c& p0, u32x4c& p1, u32x4c& p2) {
-  float r[8], q[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { r[j] = c3_residual(a[j]); q[j] = c3_residual(r[j]); }
-  p0 = u32x4c{c3_hi_pair(__float_as_uint(a[1]), __float_as_uint(a[0])), c3_hi_pair(__float_as_uint(a[3]), __float_as_uint(a[2])),
-              c3_hi_pair(__float_as_uint(a[5]), __float_as_uint(a[4])), c3_hi_pair(__float_as_uint(a[7]), __float_as_uint(a[6]))};
-  p1 = u32x4c{c3_hi_pair(__float_as_uint(r[1]), __float_as_uint(r[0])), c3_hi_pair(__float_as_uint(r[3]), __float_as_uint(r[2])),
-              c3_hi_pair(__float_as_uint(r[5]), __float_as_uint(r[4])), c3_hi_pair(__float_as_uint(r[7]), __float_as_uint(r[6]))};
-  p2 = u32x4c{c3_hi_pair(__float_as_uint(q[1]), __float_as_uint(q[0])), c3_hi_pair(__float_as_uint(q[3]), __float_as_uint(q[2])),
-              c3_hi_pair(__float_as_uint(q[5]), __float_as_uint(q[4])), c3_hi_pair(__float_as_uint(q[7]), __float_as_uint(q[6]))};
+  for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
 // asm MFMA, accumulator tied (conv3x3_wino4b.hip explains why not the builtin)
 __device__ __forceinline__ void c3_mfma(f32x16c& c, const u32x4c a, const u32x4c b) {
@@ -170,13 +163,14 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
     if (active) {
       // lane (row l31, k-group half): eight consecutive channels per K step -- the B-operand order of the 32 x 32 x 16 MFMA
       const int m0i = (int)m0;
-      const int xo = (l31 * p.x_stride + p.x_choff + 8 * half) * 4;
+      // (the group's base in the VGPR offset: the bounds check that turns rows past M into zeros covers the VGPR and immediate offsets only -- an SGPR offset is added unchecked)
+      const int xo = ((m0i + l31) * p.x_stride + p.x_choff + 8 * half) * 4;
       float xr[KS1][8];
 #pragma unroll
       for (int s = 0; s < KS1; ++s)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, xo + (16 * s + 4 * e) * 4, __builtin_amdgcn_readfirstlane(m0i * p.x_stride * 4), 0));
+          const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, xo + (16 * s + 4 * e) * 4, 0, 0));
           xr[s][4 * e] = v.x; xr[s][4 * e + 1] = v.y; xr[s][4 * e + 2] = v.z; xr[s][4 * e + 3] = v.w;
         }
       if (p.ln_g) {     // LayerNorm in registers: a row lives in lanes l31 and l31 + 32
@@ -359,7 +353,7 @@ int lfsr_ffn_b3_launch(const float* x, int x_stride, int x_choff, const float* l
   if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) return LFSR_E_ARG;
   if (x_stride < x_choff + K1 || y_stride < y_choff + N2 || (res && res_stride < res_choff + N2)) return LFSR_E_ARG;
   const long long span = (long long)(x_stride > y_stride ? (x_stride > res_stride ? x_stride : res_stride) : (y_stride > res_stride ? y_stride : res_stride));
-  if (M * span * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  if ((M + 64) * span * 4 >= (1LL << 31)) return LFSR_E_ARG;      // (32-bit byte offsets, a last partial group of rows included)
   FfnB3Args p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.W1 = w1_packed; p.W2 = w2_packed;
   p.R = res; p.r_stride = res_stride; p.r_choff = res_choff; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff;

@@ -7,6 +7,39 @@ enum { LFSR_IN_SAME = 0, LFSR_IN_CONV3 = 1, LFSR_IN_ANG = 2, LFSR_IN_EPIH = 3, L
        LFSR_IN_CHK_H = 5, LFSR_IN_CHK_V = 6, LFSR_IN_LINE_H = 7, LFSR_IN_LINE_V = 8 };
 enum { LFSR_OUT_SAME = 0, LFSR_OUT_VIEWS = 1, LFSR_OUT_EPIH = 2, LFSR_OUT_EPIV = 3 };
 
+#if defined(__HIPCC__)
+// The exact three-term bf16 split of one PAIR of fp32 values (x = x0 + x1 + x2 by truncation), planes in MFMA operand order (element 0 in the low half).
+//   p0 = (top 16 bits of a1, top 16 bits of a0), r = a - trunc(a) (exact), p1 likewise from r, p2 from q = r - trunc(r).
+// LFSR_SPLIT_DOT2 (default 1): the residuals as ONE v_dot2c_f32_bf16 each on the plane just packed -- r0 = a0 + (-1.0) * p0.lo + 0 * p0.hi, r1 = a1 + 0 * p0.lo
+// + (-1.0) * p0.hi: every partial sum is exactly representable, so the instruction's internal order and rounding do not matter (tools/lab/dot2_split.hip: bit-equal
+// to the and / sub form on 2^26 random bit patterns over every exponent, denormals included) -- 3.5 VALU per element instead of 5.5.  The builtin (not asm) so that
+// the compiler pads the DOT-write -> VALU-read hazard (3 wait states, which inline asm does not get: found as spurious mismatches in the first lab run).
+// The selector constants go through an SGPR the compiler cannot see into: given the literal 0x0000BF80 it encodes the INLINE constant -1.0, which the hardware reads
+// as the f32 pattern 0xBF800000 for this operand -- the other half (lab: r0 came out as a0 - trunc(a1)).
+#ifndef LFSR_SPLIT_DOT2
+#define LFSR_SPLIT_DOT2 1
+#endif
+__device__ __forceinline__ void lfsr_split_pair(float a0, float a1, unsigned& p0, unsigned& p1, unsigned& p2) {
+  typedef __bf16 lfsr_bf16x2 __attribute__((ext_vector_type(2)));
+  p0 = __builtin_amdgcn_perm(__float_as_uint(a1), __float_as_uint(a0), 0x07060302u);
+#if LFSR_SPLIT_DOT2
+  unsigned klo, khi;
+  asm("s_mov_b32 %0, 0xbf80" : "=s"(klo));
+  asm("s_mov_b32 %0, 0xbf800000" : "=s"(khi));
+  const float r0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lfsr_bf16x2, p0), __builtin_bit_cast(lfsr_bf16x2, klo), a0, false);
+  const float r1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lfsr_bf16x2, p0), __builtin_bit_cast(lfsr_bf16x2, khi), a1, false);
+  p1 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  const float q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lfsr_bf16x2, p1), __builtin_bit_cast(lfsr_bf16x2, klo), r0, false);
+  const float q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(lfsr_bf16x2, p1), __builtin_bit_cast(lfsr_bf16x2, khi), r1, false);
+#else
+  const float r0 = a0 - __uint_as_float(__float_as_uint(a0) & 0xffff0000u), r1 = a1 - __uint_as_float(__float_as_uint(a1) & 0xffff0000u);
+  p1 = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+  const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+#endif
+  p2 = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+#endif
+
 #ifdef LFSR_CONV_DIAG
 // diagnostic builds only (tools/build_diag.sh): buffer that receives the conv kernels' in-kernel s_memtime stamps; its own argument, never an
 // operand slot (round 1 passed it as R2, which selected the two-residual kernel variant on a null-based descriptor: DESIGN.md, incident note)

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(BMR * 4) void k_rowgemm(RowGemmArgs p) {
     const int s4 = (int)(tile * BMR) * p.x_stride * 4;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offX[i], s4, 0));
+      const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offX[i] + s4, 0, 0));     // (VGPR offset: the bounds check does not cover an SGPR offset)
       ra[i] = make_float4(v.x, v.y, v.z, v.w);
     }
     if constexpr (LN) if (do_ln && p.pe) {
@@ -261,7 +261,7 @@ int lfsr_rowgemm_ln_launch(const float* x, int x_stride, int x_choff, int K, con
   if ((x_stride | x_choff | y_stride | y_choff) & 3 || (y2 && ((y2_stride | y2_choff) & 3)) || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
   if (x_stride < x_choff + K || y_stride < y_choff + (y2 ? split_n : N) || (y2 && y2_stride < y2_choff + N - split_n)) return LFSR_E_ARG;
   if (((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)ln_g | (uintptr_t)ln_b) & 15) return LFSR_E_ARG;
-  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  if ((M + 256) * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
   {   // default: the three-term bf16 form (rowgemm_b3.hip); LFSR_ROWGEMM=f32 keeps the fp32-MFMA kernel below (bit-identical to LayerNorm launch + fp32 row-GEMM)
     const char* rsel = lfsr_sel("LFSR_ROWGEMM");
     if (!(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !lfsr_arith_f32()) {
@@ -287,7 +287,7 @@ int lfsr_rowgemm_launch(const float* x, int x_stride, int x_choff, int K, const 
   // the epilogue stores / loads 16 B per lane: every operand row and channel offset a multiple of four floats, 16-B aligned bases
   if ((y_stride | y_choff) & 3 || (res && ((res_stride | res_choff) & 3))) return LFSR_E_ARG;
   if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)res | (uintptr_t)bias) & 15) return LFSR_E_ARG;
-  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x (caller falls back to the gather-GEMM)
+  if ((M + 256) * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;   // 32-bit byte offsets into x (caller falls back to the gather-GEMM)
   RowGemmArgs p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.bias = bias; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = slope;

@@ -12,6 +12,10 @@
 
 #include "lfsr_internal.h"
 
+#ifndef RB_ABL
+#define RB_ABL 0   // diagnostic timing builds (WRONG results; tools/build_abl.sh): 1 no LayerNorm / split VALU, 2 no MFMAs, 4 no stores (and no residual loads), 8 no row loads after the first
+#endif
+
 namespace {
 
 typedef float f32x4b __attribute__((ext_vector_type(4)));
@@ -38,15 +42,8 @@ __device__ __forceinline__ float b3_residual(float a) { return a - __uint_as_flo
 // eight consecutive floats -> their three bf16 planes in MFMA operand order (element j in half j & 1 of register j / 2)
 __device__ __forceinline__ void b3_split8(const float4 lo, const float4 hi, u32x4b& p0, u32x4b& p1, u32x4b& p2) {
   const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  float r[8], q[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { r[j] = b3_residual(a[j]); q[j] = b3_residual(r[j]); }
-  p0 = u32x4b{b3_hi_pair(__float_as_uint(a[1]), __float_as_uint(a[0])), b3_hi_pair(__float_as_uint(a[3]), __float_as_uint(a[2])),
-              b3_hi_pair(__float_as_uint(a[5]), __float_as_uint(a[4])), b3_hi_pair(__float_as_uint(a[7]), __float_as_uint(a[6]))};
-  p1 = u32x4b{b3_hi_pair(__float_as_uint(r[1]), __float_as_uint(r[0])), b3_hi_pair(__float_as_uint(r[3]), __float_as_uint(r[2])),
-              b3_hi_pair(__float_as_uint(r[5]), __float_as_uint(r[4])), b3_hi_pair(__float_as_uint(r[7]), __float_as_uint(r[6]))};
-  p2 = u32x4b{b3_hi_pair(__float_as_uint(q[1]), __float_as_uint(q[0])), b3_hi_pair(__float_as_uint(q[3]), __float_as_uint(q[2])),
-              b3_hi_pair(__float_as_uint(q[5]), __float_as_uint(q[4])), b3_hi_pair(__float_as_uint(q[7]), __float_as_uint(q[6]))};
+  for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
 
 // asm MFMA with the accumulator tied (see conv3x3_wino4b.hip: the builtin's register allocation may overlap vDst with a source partially)
@@ -66,7 +63,8 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
   // row l15 once and two k-groups: with the k-groups at +16 B inside a padded row (the first layout) rows r and r +- 1 of different k-groups shared a 16-B
   // slot -- SQ_LDS_BANK_CONFLICT was 49 % of SQ_LDS_IDX_ACTIVE; here every group covers the 16 slots of a 256-B bank row exactly once
   constexpr int PLANE = NB * K;             // bf16 per plane (no padding)
-  extern __shared__ __attribute__((aligned(16))) unsigned short swb[];     // [3 planes][K / 8 (K step, k-group)][NB rows][8]
+  extern __shared__ __attribute__((aligned(16))) unsigned short swb[];     // [3 planes][K / 8 (K step, k-group)][NB rows][8], then (LN) gamma[K], beta[K] as fp32
+  float* const sgb = reinterpret_cast<float*>(swb + 3 * PLANE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * NB;
@@ -86,6 +84,7 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
     *reinterpret_cast<u32x4b*>(swb + 1 * PLANE + slot) = w1;
     *reinterpret_cast<u32x4b*>(swb + 2 * PLANE + slot) = w2;
   }
+  if constexpr (LN) for (int i = tid; i < 2 * K; i += NTH) sgb[i] = i < K ? p.ln_g[i] : p.ln_b[i - K];      // (read per tile: LDS latency instead of an L1 round trip)
   __syncthreads();
 
   // this lane's token row of a tile and its 8-float groups: rows past M read as zero through the buffer descriptor
@@ -96,12 +95,13 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
   float4 pr[LN ? KS : 1][2];
   const bool do_ln = LN && n0 < p.ln_cols;
   auto prefetch = [&](long long tile) {
-    const int s4 = (int)(tile * BMR) * p.x_stride * 4;
+    // (the tile's base goes into the VGPR offset: the descriptor's bounds check covers the VGPR and immediate offsets only, an SGPR offset is added unchecked)
+    const int ot = offL + (int)(tile * BMR) * p.x_stride * 4;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, offL + (32 * s + 4 * e) * 4, s4, 0));
+        f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, ot + (32 * s + 4 * e) * 4, 0, 0));
         if constexpr (KV < K) if (32 * s + 32 > KV && 32 * s + 8 * g >= KV) v = f32x4g{0.f, 0.f, 0.f, 0.f};     // (the neighbouring row's values: finite, but not ours)
         xr[s][e] = make_float4(v.x, v.y, v.z, v.w);
       }
@@ -112,11 +112,39 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
       for (int s = 0; s < KS; ++s) { pr[s][0] = *reinterpret_cast<const float4*>(pp + 32 * s); pr[s][1] = *reinterpret_cast<const float4*>(pp + 32 * s + 4); }
     }
   };
+  // Output (and residual) rows through buffer descriptors as well: rows past M and column groups past N are dropped (read as zero) by the bounds check, so the
+  // tile loop is straight-line code -- the compiler can then COUNT its waits (vmcnt counts stores too, in issue order): the top of the loop waits for the prefetched
+  // rows with the NT stores of the previous tile still in flight, where the branchy form waited for vmcnt(0), i.e. for those stores to drain
+  // (profiles/r03_logs/c15_lin_abl.log: loads + stores alone 450 us, arithmetic alone 426 us, together 710 us at the LFT geometry).
+  const bool second = p.Y2 && n0 >= p.split_n;        // (block-uniform)
+  const int ys = second ? p.y2_stride : p.y_stride, yc = second ? p.y2_choff - p.split_n : p.y_choff;
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(second ? p.Y2 : p.Y, 0, (int)(p.M * ys * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R1 ? p.R1 : p.X), 0, p.R1 ? (int)(p.M * p.r1_stride * 4) : 0, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;               // (the launchers keep every extent below 2^31 bytes: OOB + a tile's base stays out of range, without wrapping)
+  unsigned offY[NT], offR[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = n0 + 16 * t + 4 * g;
+    const bool ok = n + 3 < p.N;
+    offY[t] = ok ? (unsigned)(((wave * 16 + l15) * ys + yc + n) * 4) : OOB;
+    offR[t] = ok && p.R1 ? (unsigned)(((wave * 16 + l15) * p.r1_stride + p.r1_choff + n) * 4) : OOB;
+  }
   long long tile = blockIdx.x;
-  if (tile < ntiles) prefetch(tile);
+  prefetch(tile < ntiles ? tile : ntiles);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)      // NT dropped stores: the first tile meets the loop head in the same counter state as every other one
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4b{0u, 0u, 0u, 0u}, rsY, OOB, 0, 0);
   const unsigned short* wl = swb + (g * NB + l15) * 8;         // this lane's A-operand slot: k-group g, weight row l15 (+16 rows per sub-tile, + 4 NB slots per K step)
   for (; tile < ntiles; tile += gridDim.x) {
-    if constexpr (LN) if (do_ln) {
+    // the residual rows of THIS tile, asked for before the arithmetic (older than the next prefetch: the epilogue waits for them alone)
+    const int so = (int)(tile * BMR);
+    f32x4g rv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) rv[t] = f32x4g{-0.f, -0.f, -0.f, -0.f};      // (v + -0 = v for every v, the sign of a zero included)
+    if (p.R1 && !(RB_ABL & 4))
+#pragma unroll
+      for (int t = 0; t < NT; ++t) rv[t] = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, offR[t] + (unsigned)(so * p.r1_stride * 4), 0, 0));
+    if constexpr (LN) if (do_ln && !(RB_ABL & 1)) {
       // nn.LayerNorm(K) of the lane's row: its K values sit in the four lanes (row l15, g = 0..3), 8 KS each -- an in-lane sum and two wave shuffles per pass
       float sm = 0.f;
 #pragma unroll
@@ -144,15 +172,21 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float4 gv = *reinterpret_cast<const float4*>(p.ln_g + 32 * s + 8 * g + 4 * e);
-          const float4 bv = *reinterpret_cast<const float4*>(p.ln_b + 32 * s + 8 * g + 4 * e);
+          const float4 gv = *reinterpret_cast<const float4*>(sgb + 32 * s + 8 * g + 4 * e);
+          const float4 bv = *reinterpret_cast<const float4*>(sgb + K + 32 * s + 8 * g + 4 * e);
           xr[s][e] = make_float4(xr[s][e].x * rstd * gv.x + bv.x, xr[s][e].y * rstd * gv.y + bv.y, xr[s][e].z * rstd * gv.z + bv.z, xr[s][e].w * rstd * gv.w + bv.w);
         }
     }
     u32x4b x0[KS], x1[KS], x2[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) b3_split8(xr[s][0], xr[s][1], x0[s], x1[s], x2[s]);
-    if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+    for (int s = 0; s < KS; ++s) {
+      if constexpr (RB_ABL & 1) {
+        x0[s] = u32x4b{__float_as_uint(xr[s][0].x), __float_as_uint(xr[s][0].y), __float_as_uint(xr[s][0].z), __float_as_uint(xr[s][0].w)};
+        x1[s] = u32x4b{__float_as_uint(xr[s][1].x), __float_as_uint(xr[s][1].y), __float_as_uint(xr[s][1].z), __float_as_uint(xr[s][1].w)};
+        x2[s] = x0[s];
+      } else b3_split8(xr[s][0], xr[s][1], x0[s], x1[s], x2[s]);
+    }
+    if (!(RB_ABL & 8)) prefetch(tile + gridDim.x < ntiles ? tile + gridDim.x : ntiles);      // (past the end: rows >= M, zeros without traffic)
     f32x4b acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
@@ -172,6 +206,7 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
         const u32x4b w1 = *reinterpret_cast<const u32x4b*>(wq + PLANE);
         const u32x4b w2 = *reinterpret_cast<const u32x4b*>(wq + 2 * PLANE);
         // D[channel][row]: A = the weight rows, B = the token rows.  Smallest terms first.
+        if constexpr (RB_ABL & 2) { asm volatile("" : "+v"(acc[t]) : "v"(w0), "v"(w1), "v"(w2), "v"(x0[s]), "v"(x1[s]), "v"(x2[s])); continue; }
         b3_mfma(acc[t], w2, x0[s]);
         b3_mfma(acc[t], w0, x2[s]);
         b3_mfma(acc[t], w1, x1[s]);
@@ -184,28 +219,14 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
     for (int t = 0; t < NT; t += 4)      // MFMA results -> VALU reads below (the wait the compiler would pad for a builtin), tied to the accumulators
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[t]), "+v"(acc[t + 1]), "+v"(acc[t + 2]), "+v"(acc[t + 3]));
     // epilogue: lane (row l15, g) holds channels n0 + 16 t + 4 g .. + 3 of its row
-    const long long m = tile * BMR + wave * 16 + l15;
-    const bool second = p.Y2 && n0 >= p.split_n;        // (block-uniform)
-    float* const Yp = second ? p.Y2 : p.Y;
-    const int ys = second ? p.y2_stride : p.y_stride, yc = second ? p.y2_choff - p.split_n : p.y_choff;
-    if (m < p.M) {
-      float4 rv[NT];
-      if (p.R1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int n = n0 + 16 * t + 4 * g;
-          rv[t] = n + 3 < p.N ? *reinterpret_cast<const float4*>(p.R1 + m * p.r1_stride + p.r1_choff + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
+    if (!(RB_ABL & 4) || acc[0][0] == 123.456f) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const int n = n0 + 16 * t + 4 * g;
-        if (n + 3 >= p.N) continue;
         float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
-        if (p.R1) { v[0] += rv[t].x; v[1] += rv[t].y; v[2] += rv[t].z; v[3] += rv[t].w; }
-        *reinterpret_cast<float4*>(Yp + m * ys + yc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        v[0] += rv[t].x; v[1] += rv[t].y; v[2] += rv[t].z; v[3] += rv[t].w;      // (-0 without a residual; +0 for the dropped column groups of a residual)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4b{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsY, offY[t] + (unsigned)(so * ys * 4), 0, 0);
       }
     }
   }
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
 
 template <int K, bool LN = false, int NB = 64, int KV = K>
 int launch_b3(const RowGemmB3Args& p, hipStream_t st) {
-  constexpr int smem = 3 * NB * K * 2;
+  constexpr int smem = 3 * NB * K * 2 + (LN ? 2 * K * 4 : 0);
   constexpr int per_cu = NB == 128 ? 1 : LN ? 2 : (smem <= 52 * 1024 ? 3 : 2);      // (the LN form of K = 128 needs 189 VGPRs: two 256-thread blocks per CU)
   static std::atomic<bool> attr_set[64];
   int dev = 0;
@@ -241,7 +262,8 @@ int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, con
                            float* y, int y_stride, int y_choff, long long M, int N, float slope, hipStream_t st) {
   if ((x_stride | x_choff) & 3 || N % 64 || (y_stride | y_choff) & 3 || (res && ((res_stride | res_choff) & 3))) return LFSR_E_ARG;
   if (((uintptr_t)y | (uintptr_t)x | (uintptr_t)res | (uintptr_t)w_packed) & 15) return LFSR_E_ARG;
-  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  if ((M + 128) * (long long)x_stride * 4 >= (1LL << 31) || (M + 128) * (long long)y_stride * 4 >= (1LL << 31) || (res && (M + 128) * (long long)res_stride * 4 >= (1LL << 31)))
+    return LFSR_E_ARG;      // (32-bit buffer offsets, and 2^31 as the out-of-range marker)
   RowGemmB3Args p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.R1 = res; p.r1_stride = res_stride; p.r1_choff = res_choff;
   p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = slope;
@@ -263,7 +285,8 @@ int lfsr_rowgemm_b3_ln_launch(const float* x, int x_stride, int x_choff, int K, 
   if ((x_stride | x_choff | y_stride | y_choff) & 3 || (y2 && ((y2_stride | y2_choff) & 3)) || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
   if (x_stride < x_choff + K || y_stride < y_choff + (y2 ? split_n : N) || (y2 && y2_stride < y2_choff + N - split_n)) return LFSR_E_ARG;
   if (((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)w_packed) & 15) return LFSR_E_ARG;
-  if (M * (long long)x_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  if ((M + 128) * (long long)x_stride * 4 >= (1LL << 31) || (M + 128) * (long long)y_stride * 4 >= (1LL << 31) || (y2 && (M + 128) * (long long)y2_stride * 4 >= (1LL << 31)))
+    return LFSR_E_ARG;
   RowGemmB3Args p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = 1.0f;
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.ln_cols = ln_cols; p.pe = pe; p.pe_stride = pe_stride; p.pe_rows = pe_rows; p.pe_div = pe_div;

@@ -392,15 +392,8 @@ __device__ __forceinline__ unsigned ut_hi_pair(unsigned hi_src, unsigned lo_src)
 __device__ __forceinline__ float ut_residual(float a) { return a - __uint_as_float(__float_as_uint(a) & 0xffff0000u); }
 __device__ __forceinline__ void ut_split8(const float4 lo, const float4 hi, u32x4u& p0, u32x4u& p1, u32x4u& p2) {
   const float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  float r[8], q[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { r[j] = ut_residual(a[j]); q[j] = ut_residual(r[j]); }
-  p0 = u32x4u{ut_hi_pair(__float_as_uint(a[1]), __float_as_uint(a[0])), ut_hi_pair(__float_as_uint(a[3]), __float_as_uint(a[2])),
-              ut_hi_pair(__float_as_uint(a[5]), __float_as_uint(a[4])), ut_hi_pair(__float_as_uint(a[7]), __float_as_uint(a[6]))};
-  p1 = u32x4u{ut_hi_pair(__float_as_uint(r[1]), __float_as_uint(r[0])), ut_hi_pair(__float_as_uint(r[3]), __float_as_uint(r[2])),
-              ut_hi_pair(__float_as_uint(r[5]), __float_as_uint(r[4])), ut_hi_pair(__float_as_uint(r[7]), __float_as_uint(r[6]))};
-  p2 = u32x4u{ut_hi_pair(__float_as_uint(q[1]), __float_as_uint(q[0])), ut_hi_pair(__float_as_uint(q[3]), __float_as_uint(q[2])),
-              ut_hi_pair(__float_as_uint(q[5]), __float_as_uint(q[4])), ut_hi_pair(__float_as_uint(q[7]), __float_as_uint(q[6]))};
+  for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ut_mfma(f32x4u& c, const u32x4u a, const u32x4u b) {
