@@ -12,6 +12,9 @@
 
 #include "lfsr_internal.h"
 
+#ifndef RB_VAR
+#define RB_VAR 1   // timing variants (correct results): 1 residual rows loaded in the epilogue (default: out-projection at the LFT geometry 274 us against 291 us with the loads at the top of the tile)
+#endif
 #ifndef RB_ABL
 #define RB_ABL 0   // diagnostic timing builds (WRONG results; tools/build_abl.sh): 1 no LayerNorm / split VALU, 2 no MFMAs, 4 no stores (and no residual loads), 8 no row loads after the first
 #endif
@@ -141,9 +144,12 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
     f32x4g rv[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) rv[t] = f32x4g{-0.f, -0.f, -0.f, -0.f};      // (v + -0 = v for every v, the sign of a zero included)
-    if (p.R1 && !(RB_ABL & 4))
+    auto load_res = [&]() {
+      if (p.R1 && !(RB_ABL & 4))
 #pragma unroll
-      for (int t = 0; t < NT; ++t) rv[t] = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, offR[t] + (unsigned)(so * p.r1_stride * 4), 0, 0));
+        for (int t = 0; t < NT; ++t) rv[t] = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, offR[t] + (unsigned)(so * p.r1_stride * 4), 0, 0));
+    };
+    if (!(RB_VAR & 1)) load_res();
     if constexpr (LN) if (do_ln && !(RB_ABL & 1)) {
       // nn.LayerNorm(K) of the lane's row: its K values sit in the four lanes (row l15, g = 0..3), 8 KS each -- an in-lane sum and two wave shuffles per pass
       float sm = 0.f;
@@ -219,6 +225,7 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
     for (int t = 0; t < NT; t += 4)      // MFMA results -> VALU reads below (the wait the compiler would pad for a builtin), tied to the accumulators
       asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[t]), "+v"(acc[t + 1]), "+v"(acc[t + 2]), "+v"(acc[t + 3]));
     // epilogue: lane (row l15, g) holds channels n0 + 16 t + 4 g .. + 3 of its row
+    if (RB_VAR & 1) load_res();
     if (!(RB_ABL & 4) || acc[0][0] == 123.456f) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
