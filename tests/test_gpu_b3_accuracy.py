@@ -157,3 +157,42 @@ def test_epi_branch_batch8_equals_smaller_batches():
     assert torch.isfinite(full).all()
     parts = torch.cat([run(x[0:2]), run(x[2:5]), run(x[5:8])], 0)
     assert torch.equal(full, parts)
+
+
+def test_rows_past_m_are_neither_written_nor_needed(monkeypatch):
+    """The row-streaming kernels drop rows >= M of the last tile through their buffer descriptors (the bounds check covers VGPR / immediate offsets only: the tile base
+    must not sit in the SGPR offset).  Output buffers carry a guard band of sentinel rows behind row M that must survive; the rows of x behind M hold NaN (a kernel that
+    folded them into valid rows would show it); ragged M around every tile size."""
+    lib = capi.load()
+    rng = np.random.default_rng(7)
+    K, N, G = 128, 384, 300
+    w = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
+    wp = capi.pack_conv_weight(dev(w.reshape(N, K, 1, 1)))
+    g = (1 + 0.3 * rng.standard_normal(K)).astype(np.float32); b = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    gd, bd = dev(g), dev(b)
+    w1 = (rng.standard_normal((2 * K, K)) * 0.1).astype(np.float32); w2 = (rng.standard_normal((K, 2 * K)) * 0.1).astype(np.float32)
+    w1p = capi.pack_conv_weight(dev(w1.reshape(2 * K, K, 1, 1))); w2p = capi.pack_conv_weight(dev(w2.reshape(K, 2 * K, 1, 1)))
+    for M in (1, 15, 16, 17, 63, 65, 127, 129, 255, 257, 1000, 4099):
+        x = rng.standard_normal((M + G, K)).astype(np.float32)
+        x[M:] = np.nan
+        xd = dev(x)
+        x64 = x[:M].astype(np.float64)
+        xn = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * g + b
+        # linear (with a residual), LayerNorm + in-projection (two outputs), LayerNorm + feed-forward
+        y = torch.full((M + G, 128), 7.5, device="cuda")
+        capi.check(lib.lfsr_linear_fwd(capi.dev_ptr(xd), K, 0, K, capi.dev_ptr(wp), None, capi.dev_ptr(xd), K, 0, capi.dev_ptr(y), 128, 0, M, 128, 1.0, capi.stream_ptr()), "linear")
+        yh = y.cpu().numpy()
+        assert (yh[M:] == 7.5).all(), M
+        assert np.abs(yh[:M] - (x64 @ w[:128].astype(np.float64).T + x64)).max() < 1e-4, M
+        qk = torch.full((M + G, 256), 7.5, device="cuda"); v = torch.full((M + G, 128), 7.5, device="cuda")
+        capi.check(lib.lfsr_linear_ln_fwd(capi.dev_ptr(xd), K, 0, K, capi.dev_ptr(wp), capi.dev_ptr(gd), capi.dev_ptr(bd), 1e-5, 256, None, 0, 0, 0,
+                                          capi.dev_ptr(qk), 256, 0, capi.dev_ptr(v), 128, 0, 256, M, N, capi.stream_ptr()), "linear_ln")
+        qh, vh = qk.cpu().numpy(), v.cpu().numpy()
+        assert (qh[M:] == 7.5).all() and (vh[M:] == 7.5).all(), M
+        assert np.abs(qh[:M] - xn @ w[:256].astype(np.float64).T).max() < 1e-4 and np.abs(vh[:M] - x64 @ w[256:].astype(np.float64).T).max() < 1e-4, M
+        yf = torch.full((M + G, K), 7.5, device="cuda")
+        capi.check(lib.lfsr_ffn_ln_fwd(capi.dev_ptr(xd), K, 0, capi.dev_ptr(gd), capi.dev_ptr(bd), 1e-5, capi.dev_ptr(w1p), capi.dev_ptr(w2p), capi.dev_ptr(xd), K, 0,
+                                       capi.dev_ptr(yf), K, 0, M, K, 2 * K, K, 0.0, capi.stream_ptr()), "ffn_ln")
+        fh = yf.cpu().numpy()
+        assert (fh[M:] == 7.5).all(), M
+        assert np.abs(fh[:M] - (np.maximum(xn @ w1.astype(np.float64).T, 0.0) @ w2.astype(np.float64).T + x64)).max() < 1e-4, M

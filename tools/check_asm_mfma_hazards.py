@@ -1,6 +1,8 @@
 """The three-term bf16 kernels issue their MFMAs as asm statements, so the compiler pads no wait states around them.  This reads the ISA of those files and
 checks, for every v_mfma, that no VALU instruction within the WAIT issue slots in front of it writes one of its source registers, and that no VALU / LDS / VMEM
 instruction within WAIT slots behind the LAST mfma of an accumulator chain reads its destination (s_nop N counts N + 1 slots).
+Also: every v_dot2c_f32_bf16 of the split (lfsr_split_pair) must take its selector from an SGPR -- as an inline constant (-1.0) the hardware reads the f32 pattern, i.e. the
+other half of the pair.
 usage: python tools/check_asm_mfma_hazards.py [file.hip ...]   (default: rowgemm_b3.hip ffn_b3.hip up_tail.hip epi_b3.hip)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,6 +24,13 @@ for f in files:
         lines = [l.split(";")[0].strip() for l in open(t.name)]
     ins = [l for l in lines if l and not l.startswith((".", "//")) and not l.endswith(":")]
     n_mfma = 0
+    n_dot = 0
+    for l in ins:
+        if l.startswith("v_dot2c_f32_bf16"):
+            n_dot += 1
+            ops = [o.strip() for o in l.split(None, 1)[1].split(",")]
+            if not re.fullmatch(r"s\d+", ops[1]):
+                print(f"{f}: split selector is not an SGPR:\n    {l}"); bad += 1
     for i, l in enumerate(ins):
         if not l.startswith("v_mfma") or "bf16" not in l: continue
         n_mfma += 1
@@ -54,5 +63,5 @@ for f in files:
                     print(f"{f}: read of an MFMA result {slots} slot(s) behind it:\n    {l}\n    {p}"); bad += 1
                 slots += 1
             j += 1
-    print(f"{f}: {n_mfma} bf16 MFMAs checked")
+    print(f"{f}: {n_mfma} bf16 MFMAs checked, {n_dot} v_dot2c selectors in SGPRs")
 sys.exit(1 if bad else 0)
