@@ -10,6 +10,9 @@
 
 #include "lfsr_internal.h"
 
+#ifndef FB_ABL
+#define FB_ABL 0   // diagnostic timing builds (WRONG results; tools/build_abl.sh, tools/ffn_time.py): 1 token rows loaded in the first round only, 2 LayerNorm + split in the
+#endif             // first round only, 4 no residual loads, 8 no stores, 16 no weight restaging after the first chunk
 namespace {
 
 typedef float f32x16c __attribute__((ext_vector_type(16)));
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
     const long long g = gstart + (long long)rd * gpr + wave;
     const bool active = wave < gpr && g < gstart + gn;
     const long long m0 = g * 32;
-    if (active) {
+    if (active && !((FB_ABL & 2) && rd > 0)) {
       // lane (row l31, k-group half): eight consecutive channels per K step -- the B-operand order of the 32 x 32 x 16 MFMA
       const int m0i = (int)m0;
       // (the group's base in the VGPR offset: the bounds check that turns rows past M into zeros covers the VGPR and immediate offsets only -- an SGPR offset is added unchecked)
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
       for (int s = 0; s < KS1; ++s)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, xo + (16 * s + 4 * e) * 4, 0, 0));
+          f32x4g v = {1.f, 2.f, 3.f, 4.f};
+          if (!((FB_ABL & 1) && rd > 0)) v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, xo + (16 * s + 4 * e) * 4, 0, 0));
           xr[s][4 * e] = v.x; xr[s][4 * e + 1] = v.y; xr[s][4 * e + 2] = v.z; xr[s][4 * e + 3] = v.w;
         }
       if (p.ln_g) {     // LayerNorm in registers: a row lives in lanes l31 and l31 + 32
@@ -213,7 +217,8 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
       const bool last_step = rd == rounds - 1 && c == nch - 1;
       const int cn = c + 1 < nch ? c + 1 : 0;
       unsigned short* const bufn = sw + ((step + 1) & 1) * BUFH;
-      if (!last_step) { if (pre) fetch_img(cn, 0); else fetch_chunk(cn); }   // flies under this chunk's MFMAs
+      const bool restage = !last_step && !((FB_ABL & 16) && step > 0);
+      if (restage) { if (pre) fetch_img(cn, 0); else fetch_chunk(cn); }   // flies under this chunk's MFMAs
       if (active) {
         // GEMM 1 (transposed): h[hidden][row], A = W1 rows of the chunk (lane = hidden unit l31, k-group half), B = the token planes
         f32x16c h;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
           c3_mfma(h, w1, x0[s]); c3_mfma(h, w0, x1[s]); c3_mfma(h, w0, x0[s]);
         }
         c3_settle(h);
-        if (pre && !last_step) { store_img(bufn, 0); fetch_img(cn, 1); }      // (wave-uniform; every wave of the block passes here or in the branch below)
+        if (pre && restage) { store_img(bufn, 0); fetch_img(cn, 1); }      // (wave-uniform; every wave of the block passes here or in the branch below)
         // activation + split in place: registers 8 ks .. 8 ks + 7 of the lane = hidden units 16 ks + 8 e + 4 half + r = the eight k slots of GEMM 2's step ks
         u32x4c h0[2], h1[2], h2[2];
 #pragma unroll
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
           }
         }
       }
-      if (!last_step) {
+      if (restage) {
         if (pre) { if (!active) { store_img(bufn, 0); fetch_img(cn, 1); } store_img(bufn, 1); }
         else store_chunk(bufn);
       }
@@ -275,11 +280,11 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
         f32x4g rv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rv[q] = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? rvo + (32 * t + 8 * q) * 4 : FOOB3, rs, 0));
+          rv[q] = (FB_ABL & 4) ? f32x4g{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? rvo + (32 * t + 8 * q) * 4 : FOOB3, rs, 0));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4g o = {accy[t][4 * q] + rv[q].x, accy[t][4 * q + 1] + rv[q].y, accy[t][4 * q + 2] + rv[q].z, accy[t][4 * q + 3] + rv[q].w};
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4c, o), rsY, ok ? yv + (32 * t + 8 * q) * 4 : FOOB3, ys, 0);
+          if (!(FB_ABL & 8) || o.x == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4c, o), rsY, ok ? yv + (32 * t + 8 * q) * 4 : FOOB3, ys, 0);
         }
       }
     }
