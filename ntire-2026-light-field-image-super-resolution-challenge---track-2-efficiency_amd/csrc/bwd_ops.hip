@@ -355,7 +355,7 @@ int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st) {
   p.M = g.M; p.N = g.N; p.Npad = npad32(g.N); p.A = g.A; p.AA = g.A * g.A; p.H = g.h; p.W = g.w; p.ntaps = g.ntaps; p.CH = g.CH; p.slope = 1.0f;
   if ((g.x_stride | g.x_choff) & 3) return LFSR_E_ARG;
   // fuse.0 dgrad (64 -> 144, masked by the saved concat buffer): the row-streaming kernel (LFSR_NO_ROWGEMM keeps the gather-GEMM: A/B runs)
-  if (g.in_mode == LFSR_IN_SAME && g.out_mode == LFSR_OUT_SAME && g.cin == 64 && g.N == 144 && g.ntaps == 1 && !g.R1 && g.M >= 2048 && !lfsr_sel("LFSR_NO_ROWGEMM") && !lfsr_sel("LFSR_DGRAD_PW")) {     // (LFSR_DGRAD_PW=gather: the gather-GEMM for this data gradient only -- the forward keeps its kernel)
+  if (g.in_mode == LFSR_IN_SAME && g.out_mode == LFSR_OUT_SAME && g.cin == 64 && g.N == 144 && g.ntaps == 1 && !g.R1 && g.M >= 2048 && !lfsr_sel("LFSR_NO_ROWGEMM") && !(lfsr_sel("LFSR_DGRAD_PW") && lfsr_sel("LFSR_DGRAD_PW")[0] == 'g')) {     // (LFSR_DGRAD_PW=gather: the gather-GEMM for this data gradient only -- the forward keeps its kernel)
     const int rc = lfsr_rowgemm_dgrad144_launch(g.X, g.x_stride, g.x_choff, g.Wp, g.Mk, g.mk_stride, g.mk_choff, g.mk_slope, g.Y, g.y_stride, g.y_choff, g.M, st);
     if (rc != LFSR_E_ARG) return rc;
   }

@@ -245,6 +245,14 @@ int lfsr_rowgemm_dgrad144_launch(const float* dy, int dy_stride, int dy_choff, c
   if ((dy_stride | dy_choff | dx_stride | dx_choff) & 3 || (mk && ((mk_stride | mk_choff) & 3))) return LFSR_E_ARG;
   if (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)mk | (uintptr_t)wT_packed) & 15) return LFSR_E_ARG;
   if (M * (long long)dy_stride * 4 >= (1LL << 31) || M * (long long)dx_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  {   // default: the three-term bf16 form (rowgemm_b3.hip, three 64-column panels of which the last holds 16 columns); LFSR_ROWGEMM=f32 / lfsr_set_arithmetic(f32): the kernel below
+    const char* rsel = lfsr_sel("LFSR_ROWGEMM");
+    const char* dsel = lfsr_sel("LFSR_DGRAD_PW");      // "f32": the fp32-MFMA kernel for this data gradient only (A/B runs; "gather": see bwd_ops.hip)
+    if (mk && !(rsel && (rsel[0] == 'f' || rsel[0] == '1')) && !(dsel && dsel[0] == 'f') && !lfsr_arith_f32()) {
+      const int rc = lfsr_rowgemm_b3_dgrad_launch(dy, dy_stride, dy_choff, wT_packed, mk, mk_stride, mk_choff, mk_slope, dx, dx_stride, dx_choff, M, 144, st);
+      if (rc != LFSR_E_ARG) return rc;
+    }
+  }
   RowGemmArgs p{};
   p.X = dy; p.x_stride = dy_stride; p.x_choff = dy_choff; p.Wp = wT_packed; p.Mk = mk; p.mk_stride = mk_stride; p.mk_choff = mk_choff; p.mk_slope = mk_slope;
   p.Y = dx; p.y_stride = dx_stride; p.y_choff = dx_choff; p.M = M; p.N = 144; p.slope = 1.0f;

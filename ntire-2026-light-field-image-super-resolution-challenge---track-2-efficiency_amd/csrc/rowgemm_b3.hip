@@ -28,6 +28,7 @@ struct RowGemmB3Args {
   const float* X; int x_stride; int x_choff;
   const float* Wp;       // [N rows][K] fp32 (packed, k contiguous)
   const float* R1; int r1_stride; int r1_choff;
+  int r1_mask; float mk_slope;      // r1_mask: R1 is a saved activation, y = v * (R1 > 0 ? 1 : mk_slope) (the LeakyReLU' of a data gradient) instead of y = v + R1
   float* Y; int y_stride; int y_choff;
   long long M; int N;
   float slope;
@@ -232,7 +233,11 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
         float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
-        v[0] += rv[t].x; v[1] += rv[t].y; v[2] += rv[t].z; v[3] += rv[t].w;      // (-0 without a residual; +0 for the dropped column groups of a residual)
+        if (p.r1_mask) {      // (block-uniform)
+          v[0] *= rv[t].x > 0.f ? 1.f : p.mk_slope; v[1] *= rv[t].y > 0.f ? 1.f : p.mk_slope; v[2] *= rv[t].z > 0.f ? 1.f : p.mk_slope; v[3] *= rv[t].w > 0.f ? 1.f : p.mk_slope;
+        } else {
+          v[0] += rv[t].x; v[1] += rv[t].y; v[2] += rv[t].z; v[3] += rv[t].w;      // (-0 without a residual; +0 for the dropped column groups of a residual)
+        }
         __builtin_amdgcn_raw_buffer_store_b128(u32x4b{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsY, offY[t] + (unsigned)(so * ys * 4), 0, 0);
       }
     }
@@ -282,6 +287,20 @@ int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, con
     case 144: return launch_b3<160, false, 64, 144>(p, st);      // DistgSSR's fuse.0 (DistgSSR.py:99): 144 valid of 160 operand columns
     default: return LFSR_E_ARG;
   }
+}
+
+// dx = (dy W) . lrelu'(mk): the data gradient of a 1x1 conv with 64 outputs behind a saved activation mk of N channels (DistgSSR fuse.0: N = 144; train.py:256-264 runs
+// autograd through DistgSSR.py:99); wT_packed [N][64].  LFSR_E_ARG = shape not covered (the caller keeps the fp32-MFMA kernel)
+int lfsr_rowgemm_b3_dgrad_launch(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, const float* mk, int mk_stride, int mk_choff, float mk_slope,
+                                 float* dx, int dx_stride, int dx_choff, long long M, int N, hipStream_t st) {
+  if (!dy || !wT_packed || !mk || !dx || M <= 0 || N <= 0 || N % 16) return LFSR_E_ARG;
+  if ((dy_stride | dy_choff | dx_stride | dx_choff | mk_stride | mk_choff) & 3) return LFSR_E_ARG;
+  if (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)mk | (uintptr_t)wT_packed) & 15) return LFSR_E_ARG;
+  if ((M + 128) * (long long)dy_stride * 4 >= (1LL << 31) || (M + 128) * (long long)dx_stride * 4 >= (1LL << 31) || (M + 128) * (long long)mk_stride * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  RowGemmB3Args p{};
+  p.X = dy; p.x_stride = dy_stride; p.x_choff = dy_choff; p.Wp = wT_packed; p.R1 = mk; p.r1_stride = mk_stride; p.r1_choff = mk_choff; p.r1_mask = 1; p.mk_slope = mk_slope;
+  p.Y = dx; p.y_stride = dx_stride; p.y_choff = dx_choff; p.M = M; p.N = N; p.slope = 1.0f;
+  return launch_b3<64>(p, st);
 }
 
 // LayerNorm + attention in-projection in one launch on the three-term bf16 form (argument meaning as lfsr_rowgemm_ln_launch in rowgemm.hip)
