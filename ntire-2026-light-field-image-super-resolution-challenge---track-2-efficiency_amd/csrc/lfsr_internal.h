@@ -173,6 +173,10 @@ int lfsr_rowgemm_ln_launch(const float* x, int x_stride, int x_choff, int K, con
 int lfsr_rowgemm_b3_ln_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* ln_g, const float* ln_b, float ln_eps, int ln_cols,
                               const float* pe, int pe_stride, int pe_rows, int pe_div, float* y, int y_stride, int y_choff,
                               float* y2, int y2_stride, int y2_choff, int split_n, long long M, int N, hipStream_t st);
+// lnlin_b3.hip: LayerNorm + q | k | v projection with the weights in registers and the token rows through LDS (K = 128, N = 384); LFSR_E_ARG = shape not covered
+int lfsr_lnlin_b3_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* ln_g, const float* ln_b, float ln_eps, int ln_cols,
+                         const float* pe, int pe_stride, int pe_rows, int pe_div, float* y, int y_stride, int y_choff,
+                         float* y2, int y2_stride, int y2_choff, int split_n, long long M, int N, hipStream_t st);
 int lfsr_rowgemm_b3_dgrad_launch(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, const float* mk, int mk_stride, int mk_choff, float mk_slope,
                                  float* dx, int dx_stride, int dx_choff, long long M, int N, hipStream_t st);
 int lfsr_rowgemm_b3_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* res, int res_stride, int res_choff,

@@ -313,6 +313,14 @@ int lfsr_rowgemm_b3_ln_launch(const float* x, int x_stride, int x_choff, int K, 
   if (((uintptr_t)y | (uintptr_t)y2 | (uintptr_t)x | (uintptr_t)pe | (uintptr_t)ln_g | (uintptr_t)ln_b | (uintptr_t)w_packed) & 15) return LFSR_E_ARG;
   if ((M + 128) * (long long)x_stride * 4 >= (1LL << 31) || (M + 128) * (long long)y_stride * 4 >= (1LL << 31) || (y2 && (M + 128) * (long long)y2_stride * 4 >= (1LL << 31)))
     return LFSR_E_ARG;
+  {   // K = 128, N = 384 (the q | k | v projections of EPIT and of LFT's spatial transformer): the weights-in-registers form (lnlin_b3.hip); LFSR_LNLIN=0: the panel form below
+    const char* lsel = lfsr_sel("LFSR_LNLIN");
+    if (!(lsel && lsel[0] == '0')) {
+      const int rc = lfsr_lnlin_b3_launch(x, x_stride, x_choff, K, w_packed, ln_g, ln_b, ln_eps, ln_cols, pe, pe_stride, pe_rows, pe_div, y, y_stride, y_choff,
+                                          y2, y2_stride, y2_choff, split_n, M, N, st);
+      if (rc != LFSR_E_ARG) return rc;
+    }
+  }
   RowGemmB3Args p{};
   p.X = x; p.x_stride = x_stride; p.x_choff = x_choff; p.Wp = w_packed; p.Y = y; p.y_stride = y_stride; p.y_choff = y_choff; p.M = M; p.N = N; p.slope = 1.0f;
   p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.ln_cols = ln_cols; p.pe = pe; p.pe_stride = pe_stride; p.pe_rows = pe_rows; p.pe_div = pe_div;

@@ -3,11 +3,11 @@ checks, for every v_mfma, that no VALU instruction within the WAIT issue slots i
 instruction within WAIT slots behind the LAST mfma of an accumulator chain reads its destination (s_nop N counts N + 1 slots).
 Also: every v_dot2c_f32_bf16 of the split (lfsr_split_pair) must take its selector from an SGPR -- as an inline constant (-1.0) the hardware reads the f32 pattern, i.e. the
 other half of the pair.
-usage: python tools/check_asm_mfma_hazards.py [file.hip ...]   (default: rowgemm_b3.hip ffn_b3.hip up_tail.hip epi_b3.hip)"""
+usage: python tools/check_asm_mfma_hazards.py [file.hip ...]   (default: rowgemm_b3.hip ffn_b3.hip up_tail.hip epi_b3.hip lnlin_b3.hip)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = [d for d in os.listdir(ROOT) if d.endswith("_amd")][0] + "/csrc"
-files = sys.argv[1:] or ["rowgemm_b3.hip", "ffn_b3.hip", "up_tail.hip", "epi_b3.hip"]
+files = sys.argv[1:] or ["rowgemm_b3.hip", "ffn_b3.hip", "up_tail.hip", "epi_b3.hip", "lnlin_b3.hip"]
 NEED_BEFORE, NEED_AFTER = 2, 18
 
 def regs(tok):
