@@ -16,6 +16,9 @@
 
 #include "lfsr_internal.h"
 
+#ifndef LL_STPOL
+#define LL_STPOL 0   // cache-policy bits of the output stores (2 = nt)
+#endif
 #ifndef LL_ABL
 #define LL_ABL 0   // diagnostic timing builds (WRONG results; tools/build_abl.sh): 1 no LayerNorm / split (planes written once), 2 no MFMAs, 4 no stores, 8 no row loads after the prologue
 #endif
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
           for (int ct = 0; ct < NTW; ++ct) {
             const bool second = two && 16 * (NTW * wave + ct) >= p.split_n;      // (wave-uniform)
             const unsigned ro = (unsigned)((int)m0 * (second ? p.y2_stride : p.y_stride) * 4);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, acc[rt][ct]), second ? rsY2 : rsY, offY[ct] + ro, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4l, acc[rt][ct]), second ? rsY2 : rsY, offY[ct] + ro, 0, LL_STPOL);
           }
         }
         __builtin_amdgcn_sched_barrier(0);      // (the stores stay here: sunk behind the next row tile's MFMAs they would still be in flight when their registers are written again)

@@ -196,3 +196,47 @@ def test_rows_past_m_are_neither_written_nor_needed(monkeypatch):
         fh = yf.cpu().numpy()
         assert (fh[M:] == 7.5).all(), M
         assert np.abs(fh[:M] - (np.maximum(xn @ w1.astype(np.float64).T, 0.0) @ w2.astype(np.float64).T + x64)).max() < 1e-4, M
+
+
+@pytest.mark.parametrize("ln_cols,split,with_pe", [(256, 256, True), (256, 256, False), (128, 256, True), (384, 128, False), (0, 0, False), (320, 192, True), (64, 0, False)])
+def test_lnlin_weights_in_registers_form(ln_cols, split, with_pe, monkeypatch):
+    """lnlin_b3.hip (K = 128, N = 384: the weight planes in registers, rows normed / split once through LDS) against fp64 for every mix of LayerNorm'd and raw column tiles
+    inside a wave (ln_cols = 64 / 256: one LayerNorm'd tile of a wave's three, 128 / 320: two; 0 / 384: none / all), one or two outputs, ragged M around the 32-row stage, with and
+    without a positional encoding whose row index steps with the block's stages; where the panel form (LFSR_LNLIN=0) covers the shape the two agree to rounding."""
+    lib = capi.load()
+    rng = np.random.default_rng(384 + ln_cols)
+    K, N = 128, 384
+    w = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
+    wp = capi.pack_conv_weight(dev(w.reshape(N, K, 1, 1)))
+    g = (1 + 0.3 * rng.standard_normal(K)).astype(np.float32); b = (0.2 * rng.standard_normal(K)).astype(np.float32)
+    gd, bd = dev(g), dev(b)
+    pe_rows, pe_div = 37, 3
+    pe = rng.standard_normal((pe_rows, K)).astype(np.float32)
+    ped = dev(pe)
+    for M in (1, 31, 33, 8191, 8192 + 17, 70001):
+        x = (rng.standard_normal((M, K)) + 2.0 * rng.standard_normal((M, 1))).astype(np.float32)
+        xd = dev(x)
+
+        def run():
+            if split:
+                y = torch.full((M, split), float("nan"), device="cuda"); y2 = torch.full((M, N - split), float("nan"), device="cuda")
+                capi.check(lib.lfsr_linear_ln_fwd(capi.dev_ptr(xd), K, 0, K, capi.dev_ptr(wp), capi.dev_ptr(gd), capi.dev_ptr(bd), 1e-5, ln_cols,
+                                                  capi.dev_ptr(ped) if with_pe else None, K, pe_rows, pe_div, capi.dev_ptr(y), split, 0, capi.dev_ptr(y2), N - split, 0, split,
+                                                  M, N, capi.stream_ptr()), "linear_ln")
+                return np.concatenate([y.cpu().numpy(), y2.cpu().numpy()], axis=1).astype(np.float64)
+            y = torch.full((M, N), float("nan"), device="cuda")
+            capi.check(lib.lfsr_linear_ln_fwd(capi.dev_ptr(xd), K, 0, K, capi.dev_ptr(wp), capi.dev_ptr(gd), capi.dev_ptr(bd), 1e-5, ln_cols,
+                                              capi.dev_ptr(ped) if with_pe else None, K, pe_rows, pe_div, capi.dev_ptr(y), N, 0, None, 0, 0, 0, M, N, capi.stream_ptr()), "linear_ln")
+            return y.cpu().numpy().astype(np.float64)
+        monkeypatch.delenv("LFSR_LNLIN", raising=False)
+        got = run()
+        x64 = x.astype(np.float64)
+        xp = x64 + (pe[(np.arange(M) // pe_div) % pe_rows] if with_pe else 0.0)
+        xn = (xp - xp.mean(-1, keepdims=True)) / np.sqrt(xp.var(-1, keepdims=True) + 1e-5) * g + b
+        ref = np.concatenate([xn @ w[:ln_cols].astype(np.float64).T, x64 @ w[ln_cols:].astype(np.float64).T], axis=1)
+        assert np.isfinite(got).all() and np.abs(got - ref).max() < 1e-4, (M, np.abs(got - ref).max())
+        if ln_cols % 128 == 0 and (split % 128 == 0):
+            monkeypatch.setenv("LFSR_LNLIN", "0")
+            old = run()
+            monkeypatch.delenv("LFSR_LNLIN", raising=False)
+            assert np.abs(got - old).max() < 2e-5, (M, np.abs(got - old).max())
