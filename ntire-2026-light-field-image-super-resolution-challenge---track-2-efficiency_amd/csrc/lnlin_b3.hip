@@ -16,6 +16,9 @@
 
 #include "lfsr_internal.h"
 
+#ifndef LL_PHASE
+#define LL_PHASE 0   // 1: waves 4..7 multiply first and norm / split afterwards (waves 0..3 the other way round)
+#endif
 #ifndef LL_STPOL
 #define LL_STPOL 0   // cache-policy bits of the output stores (2 = nt)
 #endif
@@ -231,9 +234,22 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
     int buf = 0;
     for (long long st = blockIdx.x; st < p.nstages; st += gridDim.x, buf ^= 1) {
       // stage st is multiplied out of buffer buf while the next one (its rows arrived during the previous multiply) is normed and split into the other
+#if LL_PHASE
+      // the two waves of a SIMD (w and w + 4) take the stage's two jobs in opposite order: while one multiplies, the other norms, splits and talks to memory
+      if (wave < 4) {
+        if (!(LL_ABL & 1) || st == blockIdx.x) produce(r, buf ^ 1);
+        if (!(LL_ABL & 8)) r = load_rows();
+        consume(st, buf, nln_tag);
+      } else {
+        consume(st, buf, nln_tag);
+        if (!(LL_ABL & 1) || st == blockIdx.x) produce(r, buf ^ 1);
+        if (!(LL_ABL & 8)) r = load_rows();
+      }
+#else
       if (!(LL_ABL & 1) || st == blockIdx.x) produce(r, buf ^ 1);
       if (!(LL_ABL & 8)) r = load_rows();
       consume(st, buf, nln_tag);
+#endif
       __syncthreads();
     }
   };
