@@ -53,43 +53,58 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
   // 512-B / 1-KB row), so they must meet in one L2: consecutive workgroups go to consecutive XCDs, hence unit id = (slot j, xcd), j = (strip-group, head) -- the
   // nheads units of a strip run at the same time on one XCD and each 128-B line comes from HBM once (with the heads as the slow dimension every line was fetched
   // once per head).  A block's units are gridDim.x apart (a multiple of 8 whenever the remap applies), so it keeps its XCD.
-  struct Unit { int head, strip; long long base; };
-  auto unit_of = [&](long long u) -> Unit {
+  struct Unit { int head, strip; int base; };
+  auto unit_of = [&](unsigned u) -> Unit {          // (32-bit throughout: the launcher keeps the unit count and every pixel index below 2^31)
     Unit U;
-    long long t;
+    unsigned t;
     if (p.remap) {
-      const long long xcd = u & 7, jx = u >> 3;
+      const unsigned xcd = u & 7, jx = u >> 3;
       U.head = (int)(jx % p.nheads);
       t = (jx / p.nheads) * 8 + xcd;
     } else {
       U.head = (int)(u % p.nheads);
       t = u / p.nheads;
     }
-    U.strip = (int)(t % p.nstrip); t /= p.nstrip;
-    const int s2 = (int)(t % p.ns2); t /= p.ns2;
-    const int s1 = (int)(t % p.ns1);
-    const long long s0 = t / p.ns1;
-    U.base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
+    U.strip = (int)(t % (unsigned)p.nstrip); t /= (unsigned)p.nstrip;
+    const unsigned s2 = t % (unsigned)p.ns2; t /= (unsigned)p.ns2;
+    const unsigned s1 = t % (unsigned)p.ns1;
+    const unsigned s0 = t / (unsigned)p.ns1;
+    U.base = (int)(s0 * (unsigned)p.bs0 + s1 * (unsigned)p.bs1 + s2 * (unsigned)p.bs2);
     return U;
   };
-  // staging of a unit's 12 key rows, in two halves: every load of a thread is issued before its first LDS store, and the NEXT unit's loads fly under this unit's MFMAs
+  // staging of a unit's 12 key rows: every load of a thread is issued before its first LDS store, and the NEXT unit's loads fly under this unit's MFMAs.
+  // Addresses are 32-bit byte offsets into buffer descriptors (the launcher keeps every tensor's extent below 2^31): a thread's item offsets relative to the strip's first
+  // staged row are worked out ONCE (the 64-bit pixel arithmetic per item and unit, and the SGPR spills it caused, were most of this kernel's VALU instructions); a unit adds its
+  // base and turns the rows outside the image into out-of-range offsets (zeros without traffic)
+  constexpr int OOBW = (int)0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Q), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.O, 0, 0x7fffffff, 0x00020000);
+  const int st1 = (int)p.st1, st2 = (int)p.st2;
   f32x4q kv[NIT], vv[NIT];
-  int kls[NIT];
+  int kls[NIT], krow[NIT], kpix[NIT];           // LDS slot (-1: none), staged row, pixel offset relative to the strip's first staged row (invalid column: none)
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int idx = tid + 256 * it;
+    const int key = idx >> 2;
+    const int row = (int)(((unsigned)key * magic) >> 16), ci = key - row * ncol;
+    const int kc = ci - 2;
+    const bool ok = idx < nitem && kc >= 0 && kc < p.n2;
+    kls[it] = idx < nitem ? row * WA_KP + ci : -1;
+    krow[it] = ok ? row : -(1 << 20);             // (an invalid column fails every row test)
+    kpix[it] = row * st1 + kc * st2;
+  }
+  const int kc4 = (tid & 3) * 16;                 // the 16-B chunk of the head's 64 B
   auto fetch = [&](const Unit& U, bool valid) {
     const int r0 = U.strip * 8 - 2;                         // token row of staged key row 0
+    const int pb = U.base + r0 * st1;                  // pixel of (staged row 0, column 0)
+    const int kb = (pb * p.k_stride + p.k_choff + U.head * 16) * 4 + kc4, vb = (pb * p.v_stride + p.v_choff + U.head * 16) * 4 + kc4;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int idx = tid + 256 * it;
-      const int c = idx & 3, key = idx >> 2;
-      const int row = (int)(((unsigned)key * magic) >> 16), ci = key - row * ncol;
-      const int kr = r0 + row, kc = ci - 2;
-      kv[it] = f32x4q{0.f, 0.f, 0.f, 0.f}; vv[it] = kv[it];
-      kls[it] = idx < nitem ? row * WA_KP + ci : -1;
-      if (valid && idx < nitem && kr >= 0 && kr < p.n1 && kc >= 0 && kc < p.n2) {
-        const long long pix = U.base + kr * p.st1 + kc * p.st2;
-        kv[it] = *reinterpret_cast<const f32x4q*>(p.K + pix * p.k_stride + p.k_choff + U.head * 16 + 4 * c);
-        vv[it] = *reinterpret_cast<const f32x4q*>(p.V + pix * p.v_stride + p.v_choff + U.head * 16 + 4 * c);
-      }
+      const bool ok = valid && (unsigned)(r0 + krow[it]) < (unsigned)p.n1;
+      kv[it] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rsK, ok ? kb + kpix[it] * (p.k_stride * 4) : OOBW, 0, 0));
+      vv[it] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rsV, ok ? vb + kpix[it] * (p.v_stride * 4) : OOBW, 0, 0));
     }
   };
   auto stash = [&]() {
@@ -103,32 +118,37 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
       }
     }
   };
+  // this lane's query / output token of tile i (wave + 4 i): row 4 al + (l15 >> 2) of the strip, column 4 b + (l15 & 3); pixel offset relative to the strip's first row
   f32x4q qreg[4];
+  int qrow[4], qpix[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tile = wave + 4 * i;
+    const int al = tile / p.ntc, b = tile - al * p.ntc;
+    const int qr = 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
+    qrow[i] = (tile < ntile && qc < p.n2) ? qr : (1 << 20);
+    qpix[i] = qr * st1 + qc * st2;
+  }
   auto fetch_q = [&](const Unit& U, bool valid) {
+    const int pb = U.base + U.strip * 8 * st1;
+    const int qb = (pb * p.q_stride + p.q_choff + U.head * 16 + 4 * g) * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int tile = wave + 4 * i;
-      qreg[i] = f32x4q{0.f, 0.f, 0.f, 0.f};
-      if (valid && tile < ntile) {
-        const int al = tile / p.ntc, b = tile - al * p.ntc;
-        const int qr = U.strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
-        const bool qok = qr < p.n1 && qc < p.n2;
-        const long long qpix = U.base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
-        qreg[i] = *reinterpret_cast<const f32x4q*>(p.Q + qpix * p.q_stride + p.q_choff + U.head * 16 + 4 * g);
-      }
+      const bool ok = valid && U.strip * 8 + qrow[i] < p.n1;
+      qreg[i] = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rsQ, ok ? qb + qpix[i] * (p.q_stride * 4) : OOBW, 0, 0));
     }
   };
 
-  long long u = blockIdx.x;
-  if (u >= p.nunits) return;                                // (block-uniform)
+  unsigned u = blockIdx.x;
+  if (u >= (unsigned)p.nunits) return;                                // (block-uniform)
   Unit U = unit_of(u);
   fetch_q(U, true);
   fetch(U, true);
   stash();
   __syncthreads();
   for (;;) {
-    const long long un = u + gridDim.x;
-    const bool more = un < p.nunits;                        // (block-uniform)
+    const unsigned un = u + gridDim.x;
+    const bool more = un < (unsigned)p.nunits;                        // (block-uniform)
     const Unit Un = unit_of(more ? un : u);
     f32x4q qcur[4];
 #pragma unroll
@@ -143,8 +163,7 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
       const int al = tile / p.ntc, b = tile - al * p.ntc;   // tile row inside the strip (0 / 1), tile column
       // this lane's query
       const int qr = U.strip * 8 + 4 * al + (l15 >> 2), qc = 4 * b + (l15 & 3);
-      const bool qok = qr < p.n1 && qc < p.n2;
-      const long long qpix = U.base + (qok ? qr : 0) * p.st1 + (qok ? qc : 0) * p.st2;
+      const bool qok = U.strip * 8 + qrow[ti] < p.n1;
       const f32x4q qb = qcur[ti] * p.scale;
       // registers r of a key tile kt hold key (row 4 al + 2 kt + (g >> 1), column 4 b + 4 (g & 1) + r) of the staged block
       const int kc0 = 4 * b - 2 + 4 * (g & 1);             // token column of register 0
@@ -192,7 +211,11 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
       den += __shfl_xor(den, 16);
       den += __shfl_xor(den, 32);
       const float inv = 1.0f / den;
-      if (qok) *reinterpret_cast<f32x4q*>(p.O + qpix * p.o_stride + p.o_choff + U.head * 16 + 4 * g) = o * inv;
+      {
+        const int ob = ((U.base + U.strip * 8 * st1) * p.o_stride + p.o_choff + U.head * 16 + 4 * g) * 4;
+        typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, o * inv), rsO, qok ? ob + qpix[ti] * (p.o_stride * 4) : OOBW, 0, 0);
+      }
     }
     if (!more) break;
     __syncthreads();                                        // every wave is done with this unit's keys
@@ -220,6 +243,12 @@ int lfsr_win_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
   p.kmax = n2 < clip ? n2 : clip;
   p.nstrip = (n1 + 7) / 8; p.ntc = (n2 + 3) / 4;
   p.scale = (1.0f / sqrtf(16.0f)) * 1.44269504088896340736f;
+  {   // 32-bit byte offsets: the farthest pixel any sequence touches, times the widest row, must stay below 2^31 (the caller keeps the VALU kernel otherwise)
+    const long long far = (long long)(ns0 - 1) * bs0 + (long long)(ns1 - 1) * bs1 + (long long)(ns2 - 1) * bs2 + (long long)(n1 + 16) * st1 + (long long)(n2 + 8) * st2;
+    const long long wide = (long long)(q_stride > k_stride ? q_stride : k_stride) > (long long)(v_stride > o_stride ? v_stride : o_stride)
+                               ? (long long)(q_stride > k_stride ? q_stride : k_stride) : (long long)(v_stride > o_stride ? v_stride : o_stride);
+    if (bs0 < 0 || bs1 < 0 || bs2 < 0 || st1 <= 0 || st2 <= 0 || (far + 64) * wide * 4 >= (1LL << 31)) return LFSR_E_ARG;
+  }
   const long long nblk = (long long)ns0 * ns1 * ns2 * p.nstrip;
   if (nblk <= 0 || nblk * nheads > 0x7fffffffLL) return LFSR_E_ARG;
   p.nheads = (unsigned)nheads;
