@@ -150,6 +150,10 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
   };
   if (pre) { fetch_img(0, 0); store_img(sw, 0); fetch_img(0, 1); store_img(sw, 1); }
   else { fetch_chunk(0); store_chunk(sw); }
+  // gamma | beta of the LayerNorm in LDS: read from global memory at the top of every round they were NEWER than the previous round's stores, and a wait for them
+  // (vmcnt: in issue order, stores counted) was a wait for those stores to drain
+  float* const sgb = reinterpret_cast<float*>(sw + 2 * BUFH);
+  if (p.ln_g) for (int i = tid; i < 2 * K1; i += 512) sgb[i] = i < K1 ? p.ln_g[i] : p.ln_b[i - K1];
   __syncthreads();
 
   typedef float f32x4g __attribute__((ext_vector_type(4)));
@@ -158,25 +162,41 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
   const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);   // null residual: loads return 0
   u32x4c x0[KS1], x1[KS1], x2[KS1];
   f32x16c accy[NT2];
+  // The token rows of round rd + 1 are asked for at the START of round rd's epilogue, in front of its residual loads and stores: their latency overlaps the residual's, and
+  // the next round does not begin by draining those stores (vmcnt counts stores, in issue order: a wait for loads issued BEHIND them would include them).  Ablation
+  // (profiles/r03_logs/c17_ffn_abl.log, M = 819 200): rows loaded in the first round only -43 of 727 us, no residual loads -45, no stores -60 more.
+  // Every wave runs the loads and the LayerNorm + split, with or without a group of rows (out-of-range offsets: zeros, no traffic): the raw rows and the planes are then
+  // defined on every path, so their registers are free where the other is live (raw rows: epilogue -> split; planes: split -> last chunk).
+  float xr[KS1][8];
+  auto load_x = [&](int rdn) {
+    const long long gq = gstart + (long long)rdn * gpr + wave;
+    const bool act = rdn < rounds && wave < gpr && gq < gstart + gn;
+    // (the group's base in the VGPR offset: the bounds check that turns rows past M into zeros covers the VGPR and immediate offsets only -- an SGPR offset is added unchecked)
+    const int xo = (((int)(gq * 32) + l31) * p.x_stride + p.x_choff + 8 * half) * 4;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        f32x4g v = {1.f, 2.f, 3.f, 4.f};
+        if (!((FB_ABL & 1) && rdn > 0)) v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, act ? xo + (16 * s + 4 * e) * 4 : FOOB3, 0, 0));
+        xr[s][4 * e] = v.x; xr[s][4 * e + 1] = v.y; xr[s][4 * e + 2] = v.z; xr[s][4 * e + 3] = v.w;
+      }
+  };
+#ifdef FB_STAG      // lab: blocks start (blockIdx & 7) * FB_STAG * 3.9 us apart -- are the rounds' memory bursts of all CUs in lockstep what the memory operations cost?
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 7) * FB_STAG; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+  load_x(0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4 * NT2; ++i)      // as many dropped stores as an epilogue issues behind its row loads: the first round meets the loop head in the same counter state
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4c{0u, 0u, 0u, 0u}, rsY, FOOB3 + 16 * i, 0, 0);      // (distinct addresses: identical stores are merged into one)
   int step = 0;
   for (int rd = 0; rd < rounds; ++rd) {
     const long long g = gstart + (long long)rd * gpr + wave;
     const bool active = wave < gpr && g < gstart + gn;
     const long long m0 = g * 32;
-    if (active && !((FB_ABL & 2) && rd > 0)) {
+    if (!((FB_ABL & 2) && rd > 0)) {
       // lane (row l31, k-group half): eight consecutive channels per K step -- the B-operand order of the 32 x 32 x 16 MFMA
-      const int m0i = (int)m0;
-      // (the group's base in the VGPR offset: the bounds check that turns rows past M into zeros covers the VGPR and immediate offsets only -- an SGPR offset is added unchecked)
-      const int xo = ((m0i + l31) * p.x_stride + p.x_choff + 8 * half) * 4;
-      float xr[KS1][8];
-#pragma unroll
-      for (int s = 0; s < KS1; ++s)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          f32x4g v = {1.f, 2.f, 3.f, 4.f};
-          if (!((FB_ABL & 1) && rd > 0)) v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, xo + (16 * s + 4 * e) * 4, 0, 0));
-          xr[s][4 * e] = v.x; xr[s][4 * e + 1] = v.y; xr[s][4 * e + 2] = v.z; xr[s][4 * e + 3] = v.w;
-        }
       if (p.ln_g) {     // LayerNorm in registers: a row lives in lanes l31 and l31 + 32
         float sm = 0.f;
 #pragma unroll
@@ -196,8 +216,8 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
         for (int s = 0; s < KS1; ++s)
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const float4 gv = *reinterpret_cast<const float4*>(p.ln_g + 16 * s + 8 * half + 4 * e);
-            const float4 bv = *reinterpret_cast<const float4*>(p.ln_b + 16 * s + 8 * half + 4 * e);
+            const float4 gv = *reinterpret_cast<const float4*>(sgb + 16 * s + 8 * half + 4 * e);
+            const float4 bv = *reinterpret_cast<const float4*>(sgb + K1 + 16 * s + 8 * half + 4 * e);
             xr[s][4 * e] = xr[s][4 * e] * rstd * gv.x + bv.x; xr[s][4 * e + 1] = xr[s][4 * e + 1] * rstd * gv.y + bv.y;
             xr[s][4 * e + 2] = xr[s][4 * e + 2] * rstd * gv.z + bv.z; xr[s][4 * e + 3] = xr[s][4 * e + 3] * rstd * gv.w + bv.w;
           }
@@ -268,25 +288,29 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
       __syncthreads();
     }
     // epilogue: lane (row l31, half) holds channels 32 t + 8 q + 4 half + r of its row: 16-B residual loads and stores through buffer descriptors
-    if (active) {
+    load_x(rd + 1);
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks these loads in between the stores below -- and a wait for them becomes a wait for stores again)
+    {     // (every wave, with every offset out of range for a wave without a group: one instruction stream, so the compiler can count the waits at the round's top)
 #pragma unroll
       for (int t = 0; t < NT2; ++t) c3_settle(accy[t]);
-      const int m0i = (int)m0, Mi = (int)p.M;
-      const bool ok = m0i + l31 < Mi;
+      const int m0i = active ? (int)m0 : 0, Mi = (int)p.M;
+      const bool ok = active && m0i + l31 < Mi;
       const int yv = (l31 * p.y_stride + p.y_choff + 4 * half) * 4, rvo = (l31 * p.r_stride + p.r_choff + 4 * half) * 4;
       const int ys = __builtin_amdgcn_readfirstlane(m0i * p.y_stride * 4), rs = __builtin_amdgcn_readfirstlane(m0i * p.r_stride * 4);
+      // every residual load of the group before the first store: a wait for a load issued behind a store would include the store's drain (one such chain per 32 columns before)
+      f32x4g rv[NT2][4];
 #pragma unroll
-      for (int t = 0; t < NT2; ++t) {
-        f32x4g rv[4];
+      for (int t = 0; t < NT2; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          rv[q] = (FB_ABL & 4) ? f32x4g{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? rvo + (32 * t + 8 * q) * 4 : FOOB3, rs, 0));
+          rv[t][q] = (FB_ABL & 4) ? f32x4g{0.f, 0.f, 0.f, 0.f} : __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? rvo + (32 * t + 8 * q) * 4 : FOOB3, rs, 0));
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4g o = {accy[t][4 * q] + rv[q].x, accy[t][4 * q + 1] + rv[q].y, accy[t][4 * q + 2] + rv[q].z, accy[t][4 * q + 3] + rv[q].w};
+          const f32x4g o = {accy[t][4 * q] + rv[t][q].x, accy[t][4 * q + 1] + rv[t][q].y, accy[t][4 * q + 2] + rv[t][q].z, accy[t][4 * q + 3] + rv[t][q].w};
           if (!(FB_ABL & 8) || o.x == 123.456f) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4c, o), rsY, ok ? yv + (32 * t + 8 * q) * 4 : FOOB3, ys, 0);
         }
-      }
     }
   }
 }
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(512) void k_ffn_presplit(const float* __restrict__ 
 
 template <int K1, int N2, bool PRE>
 int launch_ffn_b3(const FfnB3Args& p, hipStream_t st) {
-  constexpr int smem = 2 * 3 * (32 * (K1 + 8) + N2 * 40) * 2;
+  constexpr int smem = 2 * 3 * (32 * (K1 + 8) + N2 * 40) * 2 + 2 * K1 * 4;      // two weight buffers + gamma | beta
   static std::atomic<bool> attr_set[64];
   static std::atomic<int> cus[64];
   int dev = 0;
