@@ -315,6 +315,155 @@ __global__ __launch_bounds__(512) void k_ffn_b3(FfnB3Args p) {
   }
 }
 
+// The same block with EVERY chunk's weight planes resident in LDS (K1 = N2 = 64, H = 128: four chunk images of 29 KB): nothing is restaged, so the round loop needs no barrier
+// at all and the eight waves run their own row groups independently -- their loads, LayerNorm / split, MFMAs and stores drift apart and overlap, where the chunk-barrier form
+// has all eight change phase together (LFT's angular transformer: 241 us per launch with a matrix-pipe time of 76 us and a memory time of 110-130 us).
+// Needs the pre-split image (lfsr_ffn_b3_presplit); straight-line loop body with buffer descriptors (counted waits), the next group's rows asked for behind the split.
+template <int K1, int N2, int NCH>
+__global__ __launch_bounds__(512) void k_ffn_b3_res(FfnB3Args p) {
+  constexpr int KS1 = K1 / 16, NT2 = N2 / 32;
+  constexpr int R1H = K1 + 8, R2H = 40;
+  constexpr int P1 = 32 * R1H, P2 = N2 * R2H;
+  constexpr int BUFH = 3 * (P1 + P2);
+  extern __shared__ __attribute__((aligned(16))) unsigned short sw[];      // [NCH][ W1 planes [3][32][R1H] | W2 planes [3][N2][R2H] ], then gamma | beta
+  float* const sgb = reinterpret_cast<float*>(sw + NCH * BUFH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  for (int i = tid; i < NCH * BUFH / 8; i += 512) *reinterpret_cast<u32x4c*>(sw + i * 8) = *reinterpret_cast<const u32x4c*>(p.Wsplit + (long long)i * 8);
+  if (p.ln_g) for (int i = tid; i < 2 * K1; i += 512) sgb[i] = i < K1 ? p.ln_g[i] : p.ln_b[i - K1];
+  __syncthreads();
+
+  // this block's row groups (32 rows each): [gstart, gend); wave w takes gstart + w, + 8, ...
+  const long long gtot = (p.M + 31) / 32;
+  const long long gbase = gtot / gridDim.x, grem = gtot % gridDim.x;
+  const int gn = (int)(gbase + ((long long)blockIdx.x < grem ? 1 : 0));
+  const int gstart = (int)((long long)blockIdx.x * gbase + ((long long)blockIdx.x < grem ? (long long)blockIdx.x : grem));
+  const int gend = gstart + gn;
+  typedef float f32x4g __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);   // null residual: loads return 0
+  float xr[KS1][8];
+  auto load_x = [&](int g) __attribute__((always_inline)) {      // (a group past the block's last: out-of-range offsets, zeros without traffic; the group's base sits in the VGPR offset)
+    const int xo = g < gend ? ((g * 32 + l31) * p.x_stride + p.x_choff + 8 * half) * 4 : FOOB3;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsX, xo == FOOB3 ? FOOB3 : xo + (16 * s + 4 * e) * 4, 0, 0));
+        xr[s][4 * e] = v.x; xr[s][4 * e + 1] = v.y; xr[s][4 * e + 2] = v.z; xr[s][4 * e + 3] = v.w;
+      }
+  };
+  int g = gstart + wave;
+  load_x(g);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4 * NT2; ++i)      // as many dropped stores (distinct addresses) as an epilogue issues behind its row loads: the first group meets the loop head in the same counter state
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4c{0u, 0u, 0u, 0u}, rsY, FOOB3 + 16 * i, 0, 0);
+  for (; g < gend; g += 8) {
+    u32x4c x0[KS1], x1[KS1], x2[KS1];
+    if (p.ln_g) {     // LayerNorm in registers: a row lives in lanes l31 and l31 + 32 (the arithmetic of k_ffn_b3)
+      float sm = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS1; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm += xr[s][j];
+      sm += __shfl_xor(sm, 32);
+      const float mu = sm * (1.0f / K1);
+      float q2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS1; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xr[s][j] -= mu; q2 = fmaf(xr[s][j], xr[s][j], q2); }
+      q2 += __shfl_xor(q2, 32);
+      const float rstd = 1.0f / sqrtf(q2 * (1.0f / K1) + p.ln_eps);
+#pragma unroll
+      for (int s = 0; s < KS1; ++s)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float4 gv = *reinterpret_cast<const float4*>(sgb + 16 * s + 8 * half + 4 * e);
+          const float4 bv = *reinterpret_cast<const float4*>(sgb + K1 + 16 * s + 8 * half + 4 * e);
+          xr[s][4 * e] = xr[s][4 * e] * rstd * gv.x + bv.x; xr[s][4 * e + 1] = xr[s][4 * e + 1] * rstd * gv.y + bv.y;
+          xr[s][4 * e + 2] = xr[s][4 * e + 2] * rstd * gv.z + bv.z; xr[s][4 * e + 3] = xr[s][4 * e + 3] * rstd * gv.w + bv.w;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) c3_split8(xr[s], x0[s], x1[s], x2[s]);
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) asm volatile("s_nop 4" : "+v"(x0[s]), "+v"(x1[s]), "+v"(x2[s]));
+    load_x(g + 8);                                               // the wave's next group: in flight during this one's GEMMs
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16c accy[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accy[t][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) asm volatile("s_nop 4" : "+v"(accy[t]));
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      const unsigned short* buf = sw + c * BUFH;
+      // GEMM 1 (transposed): h[hidden][row], A = W1 rows of the chunk (lane = hidden unit l31, k-group half), B = the token planes
+      f32x16c h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[r] = 0.f;
+      asm volatile("s_nop 4" : "+v"(h));
+      const unsigned short* a1 = buf + l31 * R1H + 8 * half;
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+        const u32x4c w0 = *reinterpret_cast<const u32x4c*>(a1 + 16 * s);
+        const u32x4c w1 = *reinterpret_cast<const u32x4c*>(a1 + 16 * s + P1);
+        const u32x4c w2 = *reinterpret_cast<const u32x4c*>(a1 + 16 * s + 2 * P1);
+        c3_mfma(h, w2, x0[s]); c3_mfma(h, w0, x2[s]); c3_mfma(h, w1, x1[s]);
+        c3_mfma(h, w1, x0[s]); c3_mfma(h, w0, x1[s]); c3_mfma(h, w0, x0[s]);
+      }
+      c3_settle(h);
+      // activation + split in place: registers 8 ks .. 8 ks + 7 of the lane = hidden units 16 ks + 8 e + 4 half + r = the eight k slots of GEMM 2's step ks
+      u32x4c h0[2], h1[2], h2[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = h[8 * ks + j]; hv[j] = v >= 0.f ? v : v * p.slope; }
+        c3_split8(hv, h0[ks], h1[ks], h2[ks]);
+      }
+      asm volatile("s_nop 4" : "+v"(h0[0]), "+v"(h0[1]), "+v"(h1[0]), "+v"(h1[1]), "+v"(h2[0]), "+v"(h2[1]));
+      // GEMM 2 (transposed): y[n][row] += W2[n][hidden chunk] h[hidden][row]
+      const unsigned short* a2 = buf + 3 * P1 + l31 * R2H + 8 * half;
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned short* aq = a2 + t * 32 * R2H + 16 * ks;
+          const u32x4c w0 = *reinterpret_cast<const u32x4c*>(aq);
+          const u32x4c w1 = *reinterpret_cast<const u32x4c*>(aq + P2);
+          const u32x4c w2 = *reinterpret_cast<const u32x4c*>(aq + 2 * P2);
+          c3_mfma(accy[t], w2, h0[ks]); c3_mfma(accy[t], w0, h2[ks]); c3_mfma(accy[t], w1, h1[ks]);
+          c3_mfma(accy[t], w1, h0[ks]); c3_mfma(accy[t], w0, h1[ks]); c3_mfma(accy[t], w0, h0[ks]);
+        }
+      }
+    }
+    // epilogue: lane (row l31, half) holds channels 32 t + 8 q + 4 half + r of its row; every residual load in front of the first store
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) c3_settle(accy[t]);
+    const int m0i = g * 32, Mi = (int)p.M;
+    const bool ok = m0i + l31 < Mi;
+    const int yv = ((m0i + l31) * p.y_stride + p.y_choff + 4 * half) * 4, rvo = ((m0i + l31) * p.r_stride + p.r_choff + 4 * half) * 4;
+    f32x4g rv[NT2][4];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rv[t][q] = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? rvo + (32 * t + 8 * q) * 4 : FOOB3, 0, 0));
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4g o = {accy[t][4 * q] + rv[t][q].x, accy[t][4 * q + 1] + rv[t][q].y, accy[t][4 * q + 2] + rv[t][q].z, accy[t][4 * q + 3] + rv[t][q].w};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4c, o), rsY, ok ? yv + (32 * t + 8 * q) * 4 : FOOB3, 0, 0);
+      }
+  }
+}
+
 // one block per chunk: the chunk's LDS image (as store_chunk builds it) written to global memory once per weight set
 template <int K1, int N2>
 __global__ __launch_bounds__(512) void k_ffn_presplit(const float* __restrict__ W1, const float* __restrict__ W2, int H, unsigned short* __restrict__ out) {
@@ -371,6 +520,29 @@ int launch_ffn_b3(const FfnB3Args& p, hipStream_t st) {
   return LFSR_OK;
 }
 
+template <int K1, int N2, int NCH>
+int launch_ffn_b3_res(const FfnB3Args& p, hipStream_t st) {
+  constexpr int smem = NCH * 3 * (32 * (K1 + 8) + N2 * 40) * 2 + 2 * K1 * 4;
+  static_assert(smem <= 160 * 1024, "all chunks resident");
+  static std::atomic<bool> attr_set[64];
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ffn_b3_res<K1, N2, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    attr_set[dev] = true;
+  }
+  const long long groups = (p.M + 31) / 32;
+  long long grid = cus[dev];
+  if (grid > (groups + 7) / 8) grid = (groups + 7) / 8;
+  hipLaunchKernelGGL((k_ffn_b3_res<K1, N2, NCH>), dim3((unsigned)grid), dim3(512), smem, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
 }  // namespace
 
 // LFSR_E_ARG = shape not covered (the caller runs the fp32-MFMA kernel)
@@ -389,7 +561,12 @@ int lfsr_ffn_b3_launch(const float* x, int x_stride, int x_choff, const float* l
   p.M = M; p.H = H; p.slope = slope; p.ln_g = ln_g; p.ln_b = ln_b; p.ln_eps = ln_eps; p.Wsplit = (const unsigned short*)wsplit;
   p.x_bytes = (int)(M * x_stride * 4); p.y_bytes = (int)(M * y_stride * 4); p.r_bytes = res ? (int)(M * res_stride * 4) : 0;
   if (K1 == 128 && N2 == 128) return wsplit ? launch_ffn_b3<128, 128, true>(p, st) : launch_ffn_b3<128, 128, false>(p, st);
-  if (K1 == 64 && N2 == 64) return wsplit ? launch_ffn_b3<64, 64, true>(p, st) : launch_ffn_b3<64, 64, false>(p, st);
+  if (K1 == 64 && N2 == 64) {
+    // H = 128 with the pre-split image: all four chunks resident in LDS, no barrier in the loop (LFSR_FFN=chunks: the chunk-staging form)
+    const char* fsel = lfsr_sel("LFSR_FFN");
+    if (wsplit && H == 128 && !(fsel && fsel[0] == 'c')) return launch_ffn_b3_res<64, 64, 4>(p, st);
+    return wsplit ? launch_ffn_b3<64, 64, true>(p, st) : launch_ffn_b3<64, 64, false>(p, st);
+  }
   return LFSR_E_ARG;
 }
 
