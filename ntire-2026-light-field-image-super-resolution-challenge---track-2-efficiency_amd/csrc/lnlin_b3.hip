@@ -49,24 +49,32 @@ __device__ __forceinline__ void ll_split8(const float (&a)[8], u32x4l& p0, u32x4
 #pragma unroll
   for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
-// sum over the 16 lanes of a DPP row, the same bits in every lane (each level adds a pair symmetrically)
+// sum over the NG (16 or 8) lanes of a token row inside a DPP row, the same bits in every lane (each level adds a pair symmetrically)
+template <int NG>
 __device__ __forceinline__ float ll_row_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1, 0, 3, 2]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2, 3, 0, 1]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+  if (NG == 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
   return v;
 }
 
-constexpr int LL_K = 128, LL_KS = 4, LL_ROWS = 32;
-constexpr int LL_PLANE = LL_ROWS * 16 * 8;             // bf16 per plane (8 KB)
-constexpr int LL_SET = 3 * LL_PLANE, LL_BUF = 2 * LL_SET;
-constexpr int LL_SMEM = 2 * LL_BUF * 2 + 2 * LL_K * 4;  // two stages x two sets x three planes + gamma | beta
+constexpr int LL_ROWS = 32;
+// K = 128: 512 threads = 8 waves, a row = 16 lanes (k-groups) = a DPP row, N = 8 x 3 x 16 = 384.  K = 64 (LFT's angular transformer, LFT.py:236-241): 256 threads = 4 waves,
+// a row = 8 lanes, N = 4 x 3 x 16 = 192; the slot swizzle takes (row >> 1) & 7 (two rows fill a 256-B bank row)
+template <int K> struct LL {
+  static constexpr int KS = K / 32, NG = K / 8, NTH = LL_ROWS * NG, NW = NTH / 64;
+  static constexpr int PLANE = LL_ROWS * NG * 8;       // bf16 per plane
+  static constexpr int SET = 3 * PLANE, BUF = 2 * SET;
+  static constexpr int SMEM = 2 * BUF * 2 + 2 * K * 4; // two stages x two sets x three planes + gamma | beta
+  __device__ static __forceinline__ int swz(int row) { return K == 128 ? (row & 15) : ((row >> 1) & 7); }
+};
 
 // PE (compile time): a positional encoding is added in front of the LayerNorm -- as a run-time branch around two loads it cost the loop its counted waits
 // (the compiler merges the two paths' counters conservatively: the head of the loop waited for stores)
-template <int NTW, bool PE>
-__global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
+template <int K, int NTW, bool PE>
+__global__ __launch_bounds__(LL<K>::NTH) void k_lnlin_b3(LnLinArgs p) {
+  constexpr int LL_K = K, LL_KS = LL<K>::KS, LL_NG = LL<K>::NG, LL_NTH = LL<K>::NTH, LL_PLANE = LL<K>::PLANE, LL_SET = LL<K>::SET, LL_BUF = LL<K>::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned short sll[];
   float* const sgb = reinterpret_cast<float*>(sll + 2 * LL_BUF);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (in an SGPR: what depends on the wave alone branches as a scalar)
@@ -89,10 +97,10 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
   for (int ct = 0; ct < NTW; ++ct)
 #pragma unroll
     for (int s = 0; s < LL_KS; ++s) asm volatile("s_nop 4" : "+v"(wf[ct][s][0]), "+v"(wf[ct][s][1]), "+v"(wf[ct][s][2]));     // VALU write -> asm MFMA read
-  for (int i = tid; i < 2 * LL_K; i += 512) sgb[i] = i < LL_K ? p.ln_g[i] : p.ln_b[i - LL_K];
+  for (int i = tid; i < 2 * LL_K; i += LL_NTH) sgb[i] = i < LL_K ? p.ln_g[i] : p.ln_b[i - LL_K];
 
   // ---- producer role: thread = (row pr of the stage, k-group pj of eight values); a row = the 16 lanes of a DPP row
-  const int pr = tid >> 4, pj = tid & 15;
+  const int pr = tid / LL_NG, pj = tid % LL_NG;
   typedef float f32x4g __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)(p.M * p.x_stride * 4), 0x00020000);
   const int xoff = (pr * p.x_stride + p.x_choff + 8 * pj) * 4;
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
     st_load += gridDim.x;
     return r;
   };
-  unsigned short* const pdst = sll + (pr * 16 + (pj ^ (pr & 15))) * 8;      // this thread's slot in a plane
+  unsigned short* const pdst = sll + (pr * LL_NG + (pj ^ LL<K>::swz(pr))) * 8;      // this thread's slot in a plane
   auto produce = [&](const Raw& r, int buf) __attribute__((always_inline)) {
     unsigned short* d = pdst + buf * LL_BUF;
     const float a[8] = {r.x0.x, r.x0.y, r.x0.z, r.x0.w, r.x1.x, r.x1.y, r.x1.z, r.x1.w};
@@ -138,12 +146,12 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
     // nn.LayerNorm(128) of x + pe: two-pass, the row's 128 values sit in its 16 lanes
     float v[8] = {a[0] + r.e0.x, a[1] + r.e0.y, a[2] + r.e0.z, a[3] + r.e0.w, a[4] + r.e1.x, a[5] + r.e1.y, a[6] + r.e1.z, a[7] + r.e1.w};
     float sm = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    sm = ll_row_sum(sm);
+    sm = ll_row_sum<LL_NG>(sm);
     const float mu = sm * (1.0f / LL_K);
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { v[j] -= mu; q = fmaf(v[j], v[j], q); }
-    q = ll_row_sum(q);
+    q = ll_row_sum<LL_NG>(q);
     const float rstd = 1.0f / sqrtf(q * (1.0f / LL_K) + p.ln_eps);
     const float4 g0 = *reinterpret_cast<const float4*>(sgb + 8 * pj), g1 = *reinterpret_cast<const float4*>(sgb + 8 * pj + 4);
     const float4 b0 = *reinterpret_cast<const float4*>(sgb + LL_K + 8 * pj), b1 = *reinterpret_cast<const float4*>(sgb + LL_K + 8 * pj + 4);
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
   }
   const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)(p.M * p.y_stride * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsY2 = __builtin_amdgcn_make_buffer_rsrc(two ? p.Y2 : p.Y, 0, two ? (int)(p.M * p.y2_stride * 4) : 0, 0x00020000);
-  const unsigned short* const bsrc = sll + (l15 * 16) * 8;   // row l15 of a plane; + 16 rows per row tile; slot (4 s + g) ^ l15
+  const unsigned short* const bsrc = sll + (l15 * LL_NG) * 8;   // row l15 of a plane; + 16 rows per row tile; slot (4 s + g) ^ swz(row) (the same for rows l15 and l15 + 16)
   // NLN (compile time): how many of the wave's column tiles take the LayerNorm'd rows (tiles ascend: those come first, the raw ones behind) -- a run-time choice inside the
   // MFMA sequence would put register copies of the accumulators right behind the asm MFMAs, which the compiler does not know to be MFMAs (tools/check_asm_mfma_hazards.py)
   auto consume = [&](long long st, int buf, auto nln_tag) __attribute__((always_inline)) {
@@ -177,15 +185,15 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
     // (counted) wait for that store to COMPLETE -- with one set every row tile began by waiting out the stores of the one before (the "no stores" ablation build: -120 of 550 us)
     f32x4l acc[2][NTW];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int rt = q >> 2, s4 = q & 3;
+    for (int q = 0; q < 2 * LL_KS; ++q) {
+      const int rt = q / LL_KS, s4 = q % LL_KS;
       if (s4 == 0) {
 #pragma unroll
         for (int ct = 0; ct < NTW; ++ct) acc[rt][ct] = f32x4l{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ct = 0; ct < NTW; ++ct) asm volatile("s_nop 1" : "+v"(acc[rt][ct]));
       }
-      const unsigned short* bq = bb + (rt * 16 * 16 + ((4 * s4 + g) ^ l15)) * 8;
+      const unsigned short* bq = bb + (rt * 16 * LL_NG + ((4 * s4 + g) ^ LL<K>::swz(l15))) * 8;
       u32x4l xl[3], xw[3];
       if (need_ln) { xl[0] = *reinterpret_cast<const u32x4l*>(bq); xl[1] = *reinterpret_cast<const u32x4l*>(bq + LL_PLANE); xl[2] = *reinterpret_cast<const u32x4l*>(bq + 2 * LL_PLANE); }
       if (need_raw) { xw[0] = *reinterpret_cast<const u32x4l*>(bq + LL_SET); xw[1] = *reinterpret_cast<const u32x4l*>(bq + LL_SET + LL_PLANE); xw[2] = *reinterpret_cast<const u32x4l*>(bq + LL_SET + 2 * LL_PLANE); }
@@ -197,7 +205,7 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
         ll_mfma(acc[rt][ct], wf[ct][s4][2], xb[0]); ll_mfma(acc[rt][ct], wf[ct][s4][0], xb[2]); ll_mfma(acc[rt][ct], wf[ct][s4][1], xb[1]);
         ll_mfma(acc[rt][ct], wf[ct][s4][1], xb[0]); ll_mfma(acc[rt][ct], wf[ct][s4][0], xb[1]); ll_mfma(acc[rt][ct], wf[ct][s4][0], xb[0]);
       }
-      if (s4 == 3) {
+      if (s4 == LL_KS - 1) {
 #pragma unroll
         for (int ct = 0; ct < NTW; ++ct) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[rt][ct]));      // MFMA results -> the stores' data
         if (!(LL_ABL & 4) || acc[rt][0][0] == 123.456f) {
@@ -264,13 +272,35 @@ __global__ __launch_bounds__(512) void k_lnlin_b3(LnLinArgs p) {
   }
 }
 
+template <int K>
+int launch_lnlin(const LnLinArgs& p, long long nst, hipStream_t st) {
+  static std::atomic<bool> attr_set[64];
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+  if (!attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lnlin_b3<K, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LL<K>::SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lnlin_b3<K, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LL<K>::SMEM);
+    if (e != hipSuccess) return LFSR_HIP_ERR(e);
+    int v = 0;
+    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    attr_set[dev] = true;
+  }
+  long long grid = (long long)cus[dev] * (K == 128 ? 1 : 3);      // K = 64: 256-thread blocks of 49 KB, three per CU
+  if (grid > nst) grid = nst;
+  if (p.pe) hipLaunchKernelGGL((k_lnlin_b3<K, 3, true>), dim3((unsigned)grid), dim3(LL<K>::NTH), LL<K>::SMEM, st, p);
+  else hipLaunchKernelGGL((k_lnlin_b3<K, 3, false>), dim3((unsigned)grid), dim3(LL<K>::NTH), LL<K>::SMEM, st, p);
+  LFSR_CHECK_LAUNCH();
+  return LFSR_OK;
+}
+
 }  // namespace
 
-// LFSR_E_ARG = shape not covered (the caller keeps the panel form, rowgemm_b3.hip): K = 128, N = 384 (8 waves x 3 column tiles), ln_cols / split_n multiples of 16
+// LFSR_E_ARG = shape not covered (the caller keeps the panel form, rowgemm_b3.hip): (K, N) = (128, 384) or (64, 192) (waves x 3 column tiles), ln_cols / split_n multiples of 16
 int lfsr_lnlin_b3_launch(const float* x, int x_stride, int x_choff, int K, const float* w_packed, const float* ln_g, const float* ln_b, float ln_eps, int ln_cols,
                          const float* pe, int pe_stride, int pe_rows, int pe_div, float* y, int y_stride, int y_choff,
                          float* y2, int y2_stride, int y2_choff, int split_n, long long M, int N, hipStream_t st) {
-  if (K != 128 || N != 384 || !x || !w_packed || !ln_g || !ln_b || !y || M <= 0 || ln_cols < 0 || ln_cols > N || ln_cols % 16) return LFSR_E_ARG;
+  if (!((K == 128 && N == 384) || (K == 64 && N == 192)) || !x || !w_packed || !ln_g || !ln_b || !y || M <= 0 || ln_cols < 0 || ln_cols > N || ln_cols % 16) return LFSR_E_ARG;
   if (y2 && (split_n % 16 || split_n <= 0 || split_n >= N)) return LFSR_E_ARG;
   if ((x_stride | x_choff | y_stride | y_choff) & 3 || (y2 && ((y2_stride | y2_choff) & 3)) || (pe && ((pe_stride & 3) || pe_rows <= 0 || pe_div <= 0))) return LFSR_E_ARG;
   if (x_stride < x_choff + K || y_stride < y_choff + (y2 ? split_n : N) || (y2 && y2_stride < y2_choff + N - split_n)) return LFSR_E_ARG;
@@ -284,22 +314,5 @@ int lfsr_lnlin_b3_launch(const float* x, int x_stride, int x_choff, int K, const
   const long long nst = (M + LL_ROWS - 1) / LL_ROWS;
   if (nst > 0x7fffffffLL / LL_ROWS) return LFSR_E_ARG;
   p.nstages = (int)nst;
-  static std::atomic<bool> attr_set[64];
-  static std::atomic<int> cus[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
-  if (!attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lnlin_b3<3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LL_SMEM);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lnlin_b3<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LL_SMEM);
-    if (e != hipSuccess) return LFSR_HIP_ERR(e);
-    int v = 0;
-    cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-    attr_set[dev] = true;
-  }
-  long long grid = cus[dev];
-  if (grid > nst) grid = nst;
-  if (pe) hipLaunchKernelGGL((k_lnlin_b3<3, true>), dim3((unsigned)grid), dim3(512), LL_SMEM, st, p);
-  else hipLaunchKernelGGL((k_lnlin_b3<3, false>), dim3((unsigned)grid), dim3(512), LL_SMEM, st, p);
-  LFSR_CHECK_LAUNCH();
-  return LFSR_OK;
+  return K == 128 ? launch_lnlin<128>(p, nst, st) : launch_lnlin<64>(p, nst, st);
 }

@@ -198,14 +198,15 @@ def test_rows_past_m_are_neither_written_nor_needed(monkeypatch):
         assert np.abs(fh[:M] - (np.maximum(xn @ w1.astype(np.float64).T, 0.0) @ w2.astype(np.float64).T + x64)).max() < 1e-4, M
 
 
-@pytest.mark.parametrize("ln_cols,split,with_pe", [(256, 256, True), (256, 256, False), (128, 256, True), (384, 128, False), (0, 0, False), (320, 192, True), (64, 0, False)])
-def test_lnlin_weights_in_registers_form(ln_cols, split, with_pe, monkeypatch):
+@pytest.mark.parametrize("K,ln_cols,split,with_pe", [(128, 256, 256, True), (128, 256, 256, False), (128, 128, 256, True), (128, 384, 128, False), (128, 0, 0, False),
+                                                     (128, 320, 192, True), (128, 64, 0, False), (64, 128, 128, True), (64, 128, 128, False), (64, 64, 0, True), (64, 192, 64, False)])
+def test_lnlin_weights_in_registers_form(K, ln_cols, split, with_pe, monkeypatch):
     """lnlin_b3.hip (K = 128, N = 384: the weight planes in registers, rows normed / split once through LDS) against fp64 for every mix of LayerNorm'd and raw column tiles
     inside a wave (ln_cols = 64 / 256: one LayerNorm'd tile of a wave's three, 128 / 320: two; 0 / 384: none / all), one or two outputs, ragged M around the 32-row stage, with and
     without a positional encoding whose row index steps with the block's stages; where the panel form (LFSR_LNLIN=0) covers the shape the two agree to rounding."""
     lib = capi.load()
-    rng = np.random.default_rng(384 + ln_cols)
-    K, N = 128, 384
+    rng = np.random.default_rng(384 + ln_cols + K)
+    N = 3 * K                                  # (128, 384): eight waves of three column tiles; (64, 192): four (LFT's angular transformer)
     w = (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
     wp = capi.pack_conv_weight(dev(w.reshape(N, K, 1, 1)))
     g = (1 + 0.3 * rng.standard_normal(K)).astype(np.float32); b = (0.2 * rng.standard_normal(K)).astype(np.float32)
@@ -235,7 +236,7 @@ def test_lnlin_weights_in_registers_form(ln_cols, split, with_pe, monkeypatch):
         xn = (xp - xp.mean(-1, keepdims=True)) / np.sqrt(xp.var(-1, keepdims=True) + 1e-5) * g + b
         ref = np.concatenate([xn @ w[:ln_cols].astype(np.float64).T, x64 @ w[ln_cols:].astype(np.float64).T], axis=1)
         assert np.isfinite(got).all() and np.abs(got - ref).max() < 1e-4, (M, np.abs(got - ref).max())
-        if ln_cols % 128 == 0 and (split % 128 == 0):
+        if ln_cols % 128 == 0 and (split % 128 == 0) and K == 128:
             monkeypatch.setenv("LFSR_LNLIN", "0")
             old = run()
             monkeypatch.delenv("LFSR_LNLIN", raising=False)
