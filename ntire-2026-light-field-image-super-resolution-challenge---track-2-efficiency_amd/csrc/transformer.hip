@@ -125,6 +125,117 @@ __global__ __launch_bounds__(256) void k_window_attn(AttnArgs p) {
 }
 
 
+// ---- full attention over short sequences, heads of 8: LFT's angular transformer (the A*A = 25 views of one pixel; LFT.py:236-241) --------------------------------
+// k_window_attn_lds<8, 8> gave one thread a (query, head) and an online softmax: per key two 16-B LDS reads of k, two of v, a rescale of the eight accumulators and two
+// exponentials -- 243 us per launch at the LFT scene geometry with the LDS port (~150-190 us of reads) and the VALU (~140 us) both near their limits, against 150-170 us
+// of HBM time.  Here a thread owns TWO queries of one head, so every k / v read serves two, and the softmax is two-pass over the N1 scores kept in registers (no rescale,
+// one exponential per score); a block takes AP sequences (adjacent pixels: their token rows are adjacent in memory).
+template <int N1, int AP, int NTH>
+__global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ang_attn_pair(AttnArgs p, long long nseq) {      // (16 waves per CU: 128 registers)
+  constexpr int NQP = (N1 + 1) / 2;                  // query pairs
+  constexpr int HS = 20, TS = 8 * HS + 4;            // the staged layout of k_window_attn_lds<8, 8>: (key, head) = k8 | v8 | pad 4; a key's eight heads + 4
+  constexpr int SEQF = N1 * TS;                      // floats per staged sequence
+  extern __shared__ __attribute__((aligned(16))) float sang[];
+  const int tid = threadIdx.x;
+  // ---- stage K | V of the block's AP sequences: item = (sequence a, key, head, 16-B chunk c of k8 | v8); all of a thread's loads before its first LDS store
+  constexpr int NITEM = AP * N1 * 8 * 4;
+  constexpr int NIT = (NITEM + NTH - 1) / NTH;
+  static_assert(NTH >= AP * ((N1 + 1) / 2) * 8, "one thread per (sequence, head, query pair)");
+  float4 sv[NIT];
+  // the base pixels of the block's AP sequences, decoded once (three 64-bit divisions each) and shared through LDS
+  long long* const sbase = reinterpret_cast<long long*>(sang + AP * SEQF);
+  if (tid < AP) {
+    long long t = (long long)blockIdx.x * AP + tid;
+    const long long s2 = t % p.ns2; t /= p.ns2;
+    const long long s1 = t % p.ns1;
+    const long long s0 = t / p.ns1;
+    sbase[tid] = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
+  }
+  __syncthreads();
+  auto seq_base = [&](int a) -> long long { return sbase[a]; };
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + NTH * it;
+    sv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = i & 3, h = (i >> 2) & 7, r = i >> 5, key = r % N1, a = r / N1;
+    const long long sq = (long long)blockIdx.x * AP + a;
+    if (i < NITEM && sq < nseq) {
+      const long long pix = seq_base(a) + key * p.st1;
+      const float* src = c < 2 ? p.K + pix * p.k_stride + p.k_choff + h * 8 + c * 4 : p.V + pix * p.v_stride + p.v_choff + h * 8 + (c - 2) * 4;
+      sv[it] = *reinterpret_cast<const float4*>(src);
+    }
+  }
+  // this thread's queries: (sequence a, head h, tokens 2 qp and 2 qp + 1)
+  const int qp = tid % NQP, h = (tid / NQP) & 7, a = tid / (NQP * 8);
+  const long long sq = (long long)blockIdx.x * AP + a;
+  const bool act = a < AP && sq < nseq;
+  const bool two = 2 * qp + 1 < N1;
+  float q0[8], q1[8];
+  long long qpix = 0;
+  if (act) {
+    qpix = seq_base(a) + 2 * qp * p.st1;
+    const float4* qa = reinterpret_cast<const float4*>(p.Q + qpix * p.q_stride + p.q_choff + h * 8);
+    const float4* qb = reinterpret_cast<const float4*>(p.Q + (qpix + (two ? p.st1 : 0)) * p.q_stride + p.q_choff + h * 8);
+    const float4 a0 = qa[0], a1 = qa[1], b0 = qb[0], b1 = qb[1];
+    q0[0] = a0.x; q0[1] = a0.y; q0[2] = a0.z; q0[3] = a0.w; q0[4] = a1.x; q0[5] = a1.y; q0[6] = a1.z; q0[7] = a1.w;
+    q1[0] = b0.x; q1[1] = b0.y; q1[2] = b0.z; q1[3] = b0.w; q1[4] = b1.x; q1[5] = b1.y; q1[6] = b1.z; q1[7] = b1.w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { q0[i] *= p.scale2; q1[i] *= p.scale2; }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + NTH * it;
+    if (i < NITEM) {
+      const int c = i & 3, hh = (i >> 2) & 7, r = i >> 5, key = r % N1, aa = r / N1;
+      *reinterpret_cast<float4*>(sang + aa * SEQF + key * TS + hh * HS + c * 4) = sv[it];
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  const float* kvb = sang + a * SEQF + h * HS;
+  // pass 1: the scores of both queries (the dot products in the order of k_window_attn_lds: bit-identical scores), their maxima
+  float s0[N1], s1[N1];
+  float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+  for (int key = 0; key < N1; ++key) {
+    const float4 ka = *reinterpret_cast<const float4*>(kvb + key * TS), kb = *reinterpret_cast<const float4*>(kvb + key * TS + 4);
+    float x = 0.f, y = 0.f;
+    x = fmaf(q0[0], ka.x, x); x = fmaf(q0[1], ka.y, x); x = fmaf(q0[2], ka.z, x); x = fmaf(q0[3], ka.w, x);
+    x = fmaf(q0[4], kb.x, x); x = fmaf(q0[5], kb.y, x); x = fmaf(q0[6], kb.z, x); x = fmaf(q0[7], kb.w, x);
+    y = fmaf(q1[0], ka.x, y); y = fmaf(q1[1], ka.y, y); y = fmaf(q1[2], ka.z, y); y = fmaf(q1[3], ka.w, y);
+    y = fmaf(q1[4], kb.x, y); y = fmaf(q1[5], kb.y, y); y = fmaf(q1[6], kb.z, y); y = fmaf(q1[7], kb.w, y);
+    s0[key] = x; s1[key] = y;
+    if (key % 3 == 2 || key == N1 - 1)
+      asm volatile("" : "+v"(s0[key]), "+v"(s1[key]), "+v"(s0[key > 0 ? key - 1 : 0]), "+v"(s1[key > 0 ? key - 1 : 0]), "+v"(s0[key > 1 ? key - 2 : 0]), "+v"(s1[key > 1 ? key - 2 : 0]) : : "memory");      // (three keys at a time: both scores of a key before the next group's: left alone the scheduler runs the pass per query and keeps -- spills -- every k row in between)
+    m0 = fmaxf(m0, x); m1 = fmaxf(m1, y);
+  }
+  // pass 2: base-2 softmax (q carries log2 e) and P V
+  float acc0[8], acc1[8], den0 = 0.f, den1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+  for (int key = 0; key < N1; ++key) {
+    const float4 va = *reinterpret_cast<const float4*>(kvb + key * TS + 8), vb = *reinterpret_cast<const float4*>(kvb + key * TS + 12);
+    const float w0 = __builtin_amdgcn_exp2f(s0[key] - m0), w1 = __builtin_amdgcn_exp2f(s1[key] - m1);
+    den0 += w0; den1 += w1;
+    acc0[0] = fmaf(w0, va.x, acc0[0]); acc0[1] = fmaf(w0, va.y, acc0[1]); acc0[2] = fmaf(w0, va.z, acc0[2]); acc0[3] = fmaf(w0, va.w, acc0[3]);
+    acc0[4] = fmaf(w0, vb.x, acc0[4]); acc0[5] = fmaf(w0, vb.y, acc0[5]); acc0[6] = fmaf(w0, vb.z, acc0[6]); acc0[7] = fmaf(w0, vb.w, acc0[7]);
+    acc1[0] = fmaf(w1, va.x, acc1[0]); acc1[1] = fmaf(w1, va.y, acc1[1]); acc1[2] = fmaf(w1, va.z, acc1[2]); acc1[3] = fmaf(w1, va.w, acc1[3]);
+    acc1[4] = fmaf(w1, vb.x, acc1[4]); acc1[5] = fmaf(w1, vb.y, acc1[5]); acc1[6] = fmaf(w1, vb.z, acc1[6]); acc1[7] = fmaf(w1, vb.w, acc1[7]);
+    if (key % 3 == 2 || key == N1 - 1)
+    asm volatile("" : "+v"(acc0[0]), "+v"(acc0[1]), "+v"(acc0[2]), "+v"(acc0[3]), "+v"(acc0[4]), "+v"(acc0[5]), "+v"(acc0[6]), "+v"(acc0[7]),
+                      "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]), "+v"(acc1[4]), "+v"(acc1[5]), "+v"(acc1[6]), "+v"(acc1[7]) : : "memory");      // (as above: every update of this key here)
+  }
+  const float i0 = 1.0f / den0, i1 = 1.0f / den1;
+  float4* oa = reinterpret_cast<float4*>(p.O + qpix * p.o_stride + p.o_choff + h * 8);
+  oa[0] = make_float4(acc0[0] * i0, acc0[1] * i0, acc0[2] * i0, acc0[3] * i0); oa[1] = make_float4(acc0[4] * i0, acc0[5] * i0, acc0[6] * i0, acc0[7] * i0);
+  if (two) {
+    float4* ob = reinterpret_cast<float4*>(p.O + (qpix + p.st1) * p.o_stride + p.o_choff + h * 8);
+    ob[0] = make_float4(acc1[0] * i1, acc1[1] * i1, acc1[2] * i1, acc1[3] * i1); ob[1] = make_float4(acc1[4] * i1, acc1[5] * i1, acc1[6] * i1, acc1[7] * i1);
+  }
+}
+
+
 // ---- windowed attention, LDS-tiled ------------------------------------------------------------------------------------------
 // One block = a tile of query tokens (T1 consecutive t1 rows x all n2 columns of one sequence) x HB heads.  The K and V
 // slices (HD floats each per head) of every key the tile can see -- rows [t1_lo - l1, t1_hi + r1) clipped, all columns -- are
@@ -399,6 +510,22 @@ int lfsr_window_attn_fwd(const float* q, int q_stride, int q_choff, const float*
   // once; the L1-served kernel below re-reads them for every query (it ran at the L1's 64 B/clk: 0.43 ms per launch at 32 patches).  LFSR_ATTN_ANG=l1 keeps it (A/B runs)
   if (hd == 8 && nheads == 8 && n2 == 1 && l1 >= n1 && r1 >= n1 && n1 <= 64 && !lfsr_sel("LFSR_ATTN_L1")) {
     const char* asel = lfsr_sel("LFSR_ATTN_ANG");
+    if (n1 == 25 && !asel) {      // A = 5: two queries per thread, two-pass softmax, four pixels per 512-thread block (two pixels per 256-thread block: 220 against 213 us) (LFSR_ATTN_ANG=lds / loop / l1: the earlier forms)
+      constexpr int AP = 4, NTH = 512, TS8 = 8 * 20 + 4;
+      constexpr int smem = AP * 25 * TS8 * 4 + AP * 8;
+      static std::atomic<bool> attr_set[64];
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
+      if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ang_attn_pair<25, AP, NTH>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return LFSR_HIP_ERR(e);
+        attr_set[dev] = true;
+      }
+      const long long nseq = (long long)ns0 * ns1 * ns2;
+      hipLaunchKernelGGL((k_ang_attn_pair<25, AP, NTH>), dim3((unsigned)((nseq + AP - 1) / AP)), dim3(NTH), smem, lfsr_stream(stream), p, nseq);
+      LFSR_CHECK_LAUNCH();
+      return LFSR_OK;
+    }
     if (!(asel && asel[0] == 'l' && asel[1] == '1')) {
       p.loop_stage = asel && asel[0] == 'l' && asel[1] == 'o';
       constexpr int TS8 = 8 * 20 + 4;

@@ -2,7 +2,7 @@
 export LFSR_LAB=1
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd $R; mkdir -p gpurun_out/r3
-python -m pytest tests/test_gpu_b3_accuracy.py tests/test_gpu_lft.py tests/test_gpu_epit.py -x -q -m gpu > gpurun_out/r3/c25_tests.log 2>&1 || { tail -40 gpurun_out/r3/c25_tests.log; exit 1; }
+python -m pytest tests/test_gpu_lft.py -x -q -m gpu > gpurun_out/r3/c25_tests.log 2>&1 || { tail -40 gpurun_out/r3/c25_tests.log; exit 1; }
 tail -2 gpurun_out/r3/c25_tests.log
 O=$R/gpurun_out/r3/c25; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
