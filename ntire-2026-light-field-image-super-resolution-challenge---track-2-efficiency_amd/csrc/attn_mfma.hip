@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
-      S[kt] = f32x4a{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      // (S[kt] of a key tile outside [ktlo, kthi] is never read: the second loop skips the same tiles -- initialising it cost a register copy per element on the skipped path)
       if (kt >= ktlo && kt <= kthi) {
         const int krow = kt * 16 + l15;
         const f32x4a ka = *reinterpret_cast<const f32x4a*>(sK + krow * 16 + (((g + (krow >> 2)) & 3) << 2));
