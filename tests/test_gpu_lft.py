@@ -58,11 +58,13 @@ def test_spatial_window_attention_vs_masked_mha():
     assert np.abs(o.cpu().numpy() - ref).max() < 1e-5
 
 
-def test_angular_attention_vs_mha():
+@pytest.mark.parametrize("B,A,h,w", [(2, 3, 4, 6), (1, 5, 3, 5), (2, 5, 8, 8)])
+def test_angular_attention_vs_mha(B, A, h, w):
     """AngTrans attention (LFT.py:236-241): the A*A views at one (y, x) are the sequence, 8 heads of 8, no mask; q | k read from one 128-wide buffer, token stride = one
-    view image -- the strided addressing lft.cpp uses -- against dense fp64 multi-head attention"""
+    view image -- the strided addressing lft.cpp uses -- against dense fp64 multi-head attention.  A = 5 runs k_ang_attn_pair (two queries per thread, four pixels per
+    block: 15 sequences leave a block with three), A = 3 the LDS-tiled kernel"""
     lib = capi.load()
-    B, A, h, w, E, NH = 2, 3, 4, 6, 64, 8
+    E, NH = 64, 8
     AA, HW = A * A, h * w
     npix = B * AA * HW
     q, k, v = [(np.random.default_rng(s).standard_normal((npix, E))).astype(np.float32) for s in (11, 12, 13)]
