@@ -79,6 +79,26 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define W4_SWZ 0      // 1: staged halo pixels XOR-swizzled by column bit 2 so the producers' patch reads (ds_read_b32, 4 tiles per wave) are conflict-free
 #endif
 
+#ifndef W4_DRAIN
+#define W4_DRAIN 1    // 1: the producers drain the previous tile's exchange plane BEFORE barrier A (while they would wait for the consumers to get there) instead of
+                      // behind the V writes, where its four LDS round trips sat on the path that the consumers wait for at the chunk barrier
+#endif
+#ifndef W4_EPF
+#define W4_EPF 1      // 1 (needs W4_DRAIN): the epilogue operand (residual / saved activation) of plane c + 1 is requested right after plane c has been drained: a whole
+                      // chunk step ahead of its use instead of a few hundred cycles
+#endif
+#ifndef W4_XB
+#define W4_XB 1       // 1 (needs W4_DRAIN): no chunk barrier behind a tile's last chunk -- the exchange barrier that follows At M A publishes the next tile's first V chunk too
+                      // (the producers drained plane 3 before barrier A of that step, so the consumers may write the planes as soon as their MFMAs are done)
+#endif
+#ifndef W4_ANW
+#define W4_ANW 1      // 1: the consumers join barrier A (which orders the PRODUCERS' halo stores and patch reads) without draining their own LDS reads first
+#endif
+#ifndef W4_PSYNC
+#define W4_PSYNC 0    // 1: barrier A (halo staged -> patch reads) concerns the four producer waves only: they meet at a counter in LDS and the consumers' MFMA stream
+                      // runs from one chunk barrier to the next without stopping (5 instead of 9 s_barrier per tile for them)
+#endif
+
 #ifdef LFSR_CONV_DIAG
 // diagnostic build only: the first consumer wave and the first producer wave accumulate s_memtime deltas per segment into the
 // buffer set by lfsr_diag_set_buffer (64 floats per block: consumer 0..31, producer 32..63; producer segment k of step c = 32 + 8 c + k)
@@ -87,6 +107,16 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #else
 #define STAMP(k) do { } while (0)
 #define PSTAMP(k) do { } while (0)
+#endif
+
+#ifndef W4_CLK
+#define W4_CLK 0      // 1 (lab builds only): every block leaves its shader-clock and 100-MHz real-time deltas in g_w4_clk (read back by lfsr_w4_clk_read): the clock the chip held
+#endif
+#if W4_CLK
+__device__ unsigned long long g_w4_clk[2 * 1024];
+extern "C" int lfsr_w4_clk_read(unsigned long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w4_clk), sizeof(unsigned long long) * 2 * n_blocks) == hipSuccess ? 0 : -1;
+}
 #endif
 
 namespace {
@@ -98,7 +128,7 @@ constexpr int VBUF = 16 * TS;           // one parity
 #endif
 constexpr int HPIX = 10 * 34;           // raw halo of an 8 x 32 tile
 constexpr int HBUF = HPIX * 16;         // one 16-channel chunk, 64 B per pixel
-constexpr int SMEM_BYTES = (2 * VBUF + 4 * 4096 + (W4_HALO ? HBUF + 256 : 0)) * 4;   // V, epilogue exchange (one 64-pixel x 64-channel plane per output
+constexpr int SMEM_BYTES = (2 * VBUF + 4 * 4096 + (W4_HALO ? HBUF + 256 : 0) + (W4_PSYNC ? 16 : 0)) * 4;   // V, epilogue exchange (one 64-pixel x 64-channel plane per output
                                                                                       // row of the Winograd tiles), raw halo + 1 KB landing zone: 163072
 [[maybe_unused]] constexpr int INV = 1 << 30;            // "outside the image" marker of a row / column offset (operands span < 1 GiB)
 constexpr int OOB = (int)0x80000000u;
@@ -117,6 +147,7 @@ struct Wino4Args {
 };
 
 #define LDS_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BARRIER_NOWAIT() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
@@ -169,7 +200,9 @@ __device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, 
 //               LeakyReLU / mask / residuals applied, stored.  Their loads miss to HBM and their stores drain while the consumer of the
 //               same SIMD keeps the matrix pipe busy.
 // Barriers per tile: two per chunk (halo staged | V of the next chunk published, this chunk's V free) + one for the exchange buffer.
-template <bool MASK, bool HAS_E, bool HAS_L>
+// ACT: the activation as a compile-time form -- 0 none (slope 1), 1 max(v, v * slope) (0 <= slope < 1), 2 the select form (any slope): the run-time choice was
+// three scalar branches per drained 16-B unit on the producers' path.
+template <bool MASK, bool HAS_E, bool HAS_L, int ACT>
 __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const sV = smem;                 // V[2][16 tiles][16 ch][36]
@@ -188,6 +221,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   float* dbgbuf = p.dbg;
 #endif
 
+#if W4_CLK
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #if W4_PRIO
   if ((__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) != (W4_SWAP != 0)) __builtin_amdgcn_s_setprio(W4_PRIO);
 #endif
@@ -243,6 +279,24 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(hdst[i]) = hv[i];
     };
+#if W4_PSYNC
+    // the producers' own meeting point: a counter in LDS that only grows (LDS operations of a wave execute in order, so a wave's add follows its halo stores)
+    unsigned* const pcnt = reinterpret_cast<unsigned*>(sH + HBUF + 256);
+    int psync_target = 0;
+    auto psync = [&]() {
+      psync_target += 4;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(pcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      for (int it = 0; it < (1 << 16); ++it) {   // bounded: a lost partner ends in wrong results, not in a hang
+        const unsigned v = __hip_atomic_load(pcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((int)__builtin_amdgcn_readfirstlane(v) >= psync_target) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+#endif
     // ---- input transform of one (Winograd tile, channel) item: R[3 r + k] = patch (row r, columns 2 k, 2 k + 1)
     const float* const hR = sH + ((4 * pty) * 34 + 4 * ptx) * 16 + c16;
     f32x2 R[18];
@@ -296,41 +350,45 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     __amdgpu_buffer_rsrc_t rsYp = img_rsrc(nullptr, 0, -1), rsEp = rsYp, rsLp = rsYp;   // the PREVIOUS tile's image (none yet)
     int prow0 = 0, pcol0 = 0;                                                            // ... and its origin
     const bool ragged_w = (p.W & 31) != 0;
-    int oy[4];
-    f32x4 e[4];
-    auto drain_request = [&](int a) {
-      const int rowoff = (prow0 + a) * p.W + pcol0;   // wave-uniform pixel offset of the plane within the image
+    static_assert(!W4_EPF || W4_DRAIN, "W4_EPF needs W4_DRAIN");
+    static_assert(!W4_XB || W4_DRAIN, "W4_XB needs W4_DRAIN");
+    int oy[4] = {OOB, OOB, OOB, OOB};
+    f32x4 e[4] = {};
+    // store offsets of plane a of the tile at (row0, col0) and the request for its first epilogue operand (rsE: that tile's image)
+    auto drain_request = [&](int a, int row0, int col0, __amdgpu_buffer_rsrc_t rsE) {
+      const int rowoff = (row0 + a) * p.W + col0;   // wave-uniform pixel offset of the plane within the image
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const bool bad = ragged_w && pcol0 + dcol[i] >= p.W;
+        const bool bad = ragged_w && col0 + dcol[i] >= p.W;
         const int offy = pY[i] + rowoff * (p.y_stride * 4), offe = pE[i] + rowoff * (e_stride * 4);
         oy[i] = bad ? OOB : offy;
-        if (HAS_E) e[i] = bload4s(rsEp, bad ? OOB : offe, 0);
+        if (HAS_E) e[i] = bload4s(rsE, bad ? OOB : offe, 0);
       }
     };
     auto drain_plane = [&](int a) {
       const int rowoff = (prow0 + a) * p.W + pcol0;
+      f32x4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(dsrc[i] + a * 4096);   // one LDS round trip for the four units, not four
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(dsrc[i] + a * 4096);
-        if (p.slope == 1.f) {
-          // no activation (fuse.2, the group / cascade convs, every data gradient: 21 of the 53 forward ops): the producers' issue slots are what the tile waits for
-          // (a VALU instruction beside the streaming matrix pipe retires once per MFMA slot), so eight instructions per slot saved here are ~2 k cycles per tile
-        } else if (p.slope <= 1.f) {
+        if (ACT == 1) {
+          // max(v, v * slope) == (v >= 0 ? v : v * slope) for 0 <= slope <= 1; as an instruction, not as fmaxf: the compiler canonicalises fmaxf's LDS-loaded
+          // operand with a v_max v, v of its own (12 instead of 8 instructions per unit)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], v[k] * p.slope);   // == (v >= 0 ? v : v * slope) for 0 <= slope <= 1, two instructions per element
-        } else {
+          for (int k = 0; k < 4; ++k) { const float t = v[i][k] * p.slope; float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v[i][k]), "v"(t)); v[i][k] = r; }
+        } else if (ACT == 2) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
+          for (int k = 0; k < 4; ++k) v[i][k] = v[i][k] >= 0.f ? v[i][k] : v[i][k] * p.slope;
         }
         if (MASK) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] *= e[i][k] > 0.f ? 1.f : p.mk_slope;
+          for (int k = 0; k < 4; ++k) v[i][k] *= e[i][k] > 0.f ? 1.f : p.mk_slope;
         } else if (HAS_E) {
-          v += e[i];
+          v[i] += e[i];
         }
-        if (HAS_L) { const int offl = pL[i] + rowoff * (l_stride * 4); v += bload4s(rsLp, oy[i] == OOB ? OOB : offl, 0); }
-        if (!(W4_ABL & 32) || i == 0) bstore4(rsYp, oy[i], v);
+        if (HAS_L) { const int offl = pL[i] + rowoff * (l_stride * 4); v[i] += bload4s(rsLp, oy[i] == OOB ? OOB : offl, 0); }
+        if (!(W4_ABL & 32) || i == 0) bstore4(rsYp, oy[i], v[i]);
       }
     };
 
@@ -341,6 +399,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     halo_load(hv0, rsXc, 0);
     halo_load(hv1, rsXc, 1);
     halo_store(hv0);
+#if W4_PSYNC
+    if (tid == 0) *pcnt = 0u;
+#endif
     LDS_BARRIER();   // (A: halo of chunk 0 staged)
     read_raw();
     halo_load(hv0, rsXc, 2);
@@ -359,10 +420,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         // chunk c + 1 (chunk 0 of the next tile when c == 3): halo registers -> LDS | patch -> transform -> V of the other parity
         f32x4 (&hv)[6] = ((c + 1) & 1) ? hv1 : hv0;
         halo_store(hv);
-        drain_request(c);
+        if (!W4_EPF) drain_request(c, prow0, pcol0, rsEp);
         __builtin_amdgcn_sched_barrier(0);
+        if (W4_DRAIN) {
+          drain_plane(c);
+          __builtin_amdgcn_sched_barrier(0);
+          if (W4_EPF) {   // plane c + 1; behind plane 3 comes plane 0 of THIS tile (its epilogue operand does not depend on the conv's result)
+            if (c < 3) drain_request(c + 1, prow0, pcol0, rsEp);
+            else drain_request(0, y0, x0, img_rsrc(Ep, e_stride, img));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         PSTAMP(32 + 8 * c + 0);
+#if W4_PSYNC
+        psync();         // (A, producers only)
+#else
         LDS_BARRIER();   // (A)
+#endif
         PSTAMP(32 + 8 * c + 1);
         read_raw();
         if (c == 1) {   // chunk c + 3 is chunk 0 of the next tile from here on (no next tile: an empty descriptor, every load returns 0)
@@ -377,21 +451,21 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         if (!(W4_ABL & 4)) write_v((c + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 3);
-        drain_plane(c);
+        if (!W4_DRAIN) drain_plane(c);
         __builtin_amdgcn_sched_barrier(0);
         if (W4_LATELOAD && !(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 4);
-        LDS_BARRIER();   // (B)
+        if (!(W4_XB && c == 3)) LDS_BARRIER();   // (B)
         PSTAMP(32 + 8 * c + 5);
       }
-      LDS_BARRIER();   // this tile's results are in the exchange planes
+      LDS_BARRIER();   // this tile's results are in the exchange planes (W4_XB: and the next tile's first V chunk is published)
       PSTAMP(62);
       rsYp = img_rsrc(p.Y, p.y_stride, img); rsEp = img_rsrc(Ep, e_stride, img); rsLp = img_rsrc(Lp, l_stride, img);
       prow0 = y0; pcol0 = x0;
       if (!has_next) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { drain_request(a); drain_plane(a); }
+        for (int a = 0; a < 4; ++a) { if (!(W4_DRAIN && W4_EPF) || a > 0) drain_request(a, prow0, pcol0, rsEp); drain_plane(a); }
         break;
       }
       tile = next; img = nimg; y0 = ny0; x0 = nx0;
@@ -703,12 +777,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
             const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
             if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
             __builtin_amdgcn_sched_barrier(0);       // (keeps every LDS read two groups ahead of its use)
-            if (W4_HALO && g == (W4_LEAN ? W4_AG : 3)) { STAMP(24 + c); LDS_BARRIER(); STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
+            if (W4_HALO && !W4_PSYNC && g == (W4_LEAN ? W4_AG : 3)) { STAMP(24 + c); if (W4_ANW) BARRIER_NOWAIT(); else LDS_BARRIER(); STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
           }
         }
         STAMP(c);
         if (W4_BURST) { LDS_BARRIER(); STAMP(10 + c); }   // (B1) the producers' transform burst runs between here and B
-        LDS_BARRIER();   // V of the next chunk published; everyone is done reading this chunk's
+        if (!(W4_XB && W4_LEAN && c == 3)) LDS_BARRIER();   // V of the next chunk published; everyone is done reading this chunk's
         STAMP(16 + c);
       }
       // At M A in registers; one output row a of every Winograd tile per round -> exchange buffer
@@ -735,6 +809,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       tile += 1;
     }
   }
+#if W4_CLK
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_w4_clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
+    g_w4_clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 #ifdef LFSR_CONV_DIAG
   if (dbgbuf && threadIdx.x == (W4_SWAP ? 256 : 0))
     for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 64 + k] = (float)seg[k];
@@ -842,9 +922,11 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
   if (!attr_set[dev]) {
-    const void* fns[5] = {reinterpret_cast<const void*>(k_conv3x3_wino4<false, false, false>), reinterpret_cast<const void*>(k_conv3x3_wino4<false, true, false>),
-                          reinterpret_cast<const void*>(k_conv3x3_wino4<false, true, true>), reinterpret_cast<const void*>(k_conv3x3_wino4<true, true, false>),
-                          reinterpret_cast<const void*>(k_conv3x3_wino4<true, true, true>)};
+#define W4_FNS(A) reinterpret_cast<const void*>(k_conv3x3_wino4<false, false, false, A>), reinterpret_cast<const void*>(k_conv3x3_wino4<false, true, false, A>), \
+                  reinterpret_cast<const void*>(k_conv3x3_wino4<false, true, true, A>), reinterpret_cast<const void*>(k_conv3x3_wino4<true, true, false, A>), \
+                  reinterpret_cast<const void*>(k_conv3x3_wino4<true, true, true, A>)
+    const void* fns[15] = {W4_FNS(0), W4_FNS(1), W4_FNS(2)};
+#undef W4_FNS
     for (const void* f : fns) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
       if (e != hipSuccess) return LFSR_HIP_ERR(e);
@@ -877,11 +959,17 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
   const int slots = cus[dev];
   const unsigned grid = (unsigned)(nt < slots ? nt : slots);
   if (!mk && !r1 && r2) { p.R1 = r2; p.r1_stride = r2_stride; p.r1_choff = r2_choff; p.r1_bytes = p.r2_bytes; p.R2 = nullptr; p.r2_bytes = 0; }   // a lone residual is the first operand
-  if (mk && p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  else if (mk) hipLaunchKernelGGL((k_conv3x3_wino4<true, true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  else if (p.R1 && p.R2) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, true>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  else if (p.R1) hipLaunchKernelGGL((k_conv3x3_wino4<false, true, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
-  else hipLaunchKernelGGL((k_conv3x3_wino4<false, false, false>), dim3(grid), dim3(512), SMEM_BYTES, st, p);
+  const int act = slope == 1.f ? 0 : (slope >= 0.f && slope < 1.f ? 1 : 2);
+#define W4_GO(M, E, L) do { \
+    if (act == 0) hipLaunchKernelGGL((k_conv3x3_wino4<M, E, L, 0>), dim3(grid), dim3(512), SMEM_BYTES, st, p); \
+    else if (act == 1) hipLaunchKernelGGL((k_conv3x3_wino4<M, E, L, 1>), dim3(grid), dim3(512), SMEM_BYTES, st, p); \
+    else hipLaunchKernelGGL((k_conv3x3_wino4<M, E, L, 2>), dim3(grid), dim3(512), SMEM_BYTES, st, p); } while (0)
+  if (mk && p.R1) W4_GO(true, true, true);
+  else if (mk) W4_GO(true, true, false);
+  else if (p.R1 && p.R2) W4_GO(false, true, true);
+  else if (p.R1) W4_GO(false, true, false);
+  else W4_GO(false, false, false);
+#undef W4_GO
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
