@@ -24,59 +24,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef W4_ABL
-#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no patch loads (64 / 128: none in chunk step 3 / 1), 2 no input transform, 4 no V writes,
-                   // 8 every tile loads the same patches (cache hits only), 16 no U loads, 32 a quarter of the epilogue stores
+#define W4_ABL 0   // diagnostic timing builds (wrong results): 1 no halo loads, 2 no input transform, 4 no V writes, 16 no U loads, 32 a quarter of the epilogue
+                   // stores, 256 / 512 / 1024 every store / halo load / epilogue-operand load inside the image's first 64 KB (cache hits)
 #endif
 #ifndef W4_VRING
 #define W4_VRING 4    // depth of the V fragment ring (LDS reads W4_VRING - 1 groups ahead); must divide 36
-#endif
-#ifndef W4_PACE
-#define W4_PACE 0     // producers sleep 64 x W4_PACE cycles between the patch rows of a chunk's loads
 #endif
 #ifndef W4_URING
 #define W4_URING 12   // depth of the U fragment ring (16-B fragments in flight per wave); must divide 144
 #endif
 
-#ifndef W4_LDPOL
-#define W4_LDPOL 0    // cache-policy bits of the producers' streamed loads (gfx94x/950 buffer instructions: 1 = sc0, 2 = nt, 16 = sc1)
-#endif
 #ifndef W4_STPOL
 #define W4_STPOL (LFSR_NT_STORES ? 2 : 0)    // ... and of the output stores: nt (see lfsr_store_stream in lfsr_common.h)
 #endif
-#ifndef W4_SWAP
-#define W4_SWAP 0     // 1: waves 0..3 produce and waves 4..7 consume (which half of a workgroup is dispatched first decides VALU-issue arbitration)
-#endif
-#ifndef W4_PRIO
-#define W4_PRIO 0     // > 0: the producer waves raise their issue priority once (s_setprio), behind a provably wave-uniform branch
-#endif
-#ifndef W4_CLRELU
-#define W4_CLRELU 0   // 1: the forward activation (LeakyReLU) is applied by the consumers in At M A instead of by the producers' drain
-#endif
-#ifndef W4_LEAN
-#define W4_LEAN 1     // 1: the producers' instruction-lean form.  fp32 MFMAs and VALU instructions share the SIMD's FMA lanes: beside a streaming MFMA
-                      // wave a VALU instruction retires about once per MFMA (~30-40 cycles; LDS / memory instructions are not held up), so the producers'
-                      // VALU count per chunk step sets the pace.  Column pass of the input transform in packed math (v_pk_fma_f32 on column pairs),
-                      // per-image buffer descriptors instead of per-slot row bounds checks, per-thread offsets formed once per launch, max-form LeakyReLU.
-#endif
 #ifndef W4_AG
-#define W4_AG 24      // the MFMA group of a chunk at which the consumers join barrier A (producers: halo staged).  The producers' VALU work makes no
-                      // progress beside a streaming MFMA wave anyway, so a late A costs them nothing and the consumers never wait at it
-#endif
-#ifndef W4_LATELOAD
-#define W4_LATELOAD 1 // the producers request the halo two chunks ahead at the END of their step (the consumers are at the chunk barrier by then):
-                      // first-touch misses issued early in a step sit in the CU's memory pipeline in front of the consumers' U fragments
-#endif
-#ifndef W4_BURST
-#define W4_BURST 0    // 1: the producers' input transform (their VALU-dense part) runs in a burst of its own between two barriers, while the consumers
-                      // wait: fp32 MFMAs and VALU instructions share the SIMD's FMA lanes, and a VALU instruction issued beside a streaming MFMA wave
-                      // retires only once per MFMA (~29 cycles instead of ~6: round-2 stamps), so overlapping the two stretches both
-#endif
-#ifndef W4_MFMA4
-#define W4_MFMA4 0    // 1: every v_mfma_f32_16x16x4_f32 is issued as four v_mfma_f32_4x4x1_16b_f32 (one per k, A broadcast within groups of four
-                      // blocks by CBSZ/ABID, B lane group k broadcast by BLGP): same operands and accumulator layout, a quarter of the occupancy per instruction
-#endif
-#ifndef W4_SWZ
-#define W4_SWZ 0      // 1: staged halo pixels XOR-swizzled by column bit 2 so the producers' patch reads (ds_read_b32, 4 tiles per wave) are conflict-free
+#define W4_AG 24      // the MFMA group (0..35) of a chunk at which the consumers join barrier A (producers: halo staged); 8..30 measured the same (profiles/r04_logs)
 #endif
 
 #ifndef W4_DRAIN
@@ -94,16 +56,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef W4_ANW
 #define W4_ANW 1      // 1: the consumers join barrier A (which orders the PRODUCERS' halo stores and patch reads) without draining their own LDS reads first
 #endif
-#ifndef W4_PSYNC
-#define W4_PSYNC 0    // 1: barrier A (halo staged -> patch reads) concerns the four producer waves only: they meet at a counter in LDS and the consumers' MFMA stream
-                      // runs from one chunk barrier to the next without stopping (5 instead of 9 s_barrier per tile for them)
-#endif
 
+#ifndef W4_STAMP_A
+#define W4_STAMP_A 0  // (LFSR_CONV_DIAG builds) 1: stamps around the consumers' barrier A too -- each stamp drains the wave's LDS reads, so the stream is not what it is without them
+#endif
 #ifdef LFSR_CONV_DIAG
 // diagnostic build only: the first consumer wave and the first producer wave accumulate s_memtime deltas per segment into the
 // buffer set by lfsr_diag_set_buffer (64 floats per block: consumer 0..31, producer 32..63; producer segment k of step c = 32 + 8 c + k)
-#define STAMP(k) do { if (wave == (W4_SWAP ? 4 : 0)) { long long t_ = clock64(); seg[k] += (unsigned)(t_ - tprev); tprev = t_; } } while (0)
-#define PSTAMP(k) do { if (wave == (W4_SWAP ? 0 : 4)) { long long t_ = clock64(); seg[k] += (unsigned)(t_ - tprev); tprev = t_; } } while (0)
+#define STAMP(k) do { if (wave == 0) { long long t_ = clock64(); seg[k] += (unsigned)(t_ - tprev); tprev = t_; } } while (0)
+#define PSTAMP(k) do { if (wave == 4) { long long t_ = clock64(); seg[k] += (unsigned)(t_ - tprev); tprev = t_; } } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #define PSTAMP(k) do { } while (0)
@@ -123,14 +84,10 @@ namespace {
 
 constexpr int TS = 584;                 // floats per tile in a V buffer: 16 channels x 36 positions + 8 (2336 B = 32 mod 256)
 constexpr int VBUF = 16 * TS;           // one parity
-#ifndef W4_HALO
-#define W4_HALO 1     // 1: the producers stage a chunk's raw halo through LDS (6 x 16-B loads per thread instead of 36 dword loads)
-#endif
 constexpr int HPIX = 10 * 34;           // raw halo of an 8 x 32 tile
 constexpr int HBUF = HPIX * 16;         // one 16-channel chunk, 64 B per pixel
-constexpr int SMEM_BYTES = (2 * VBUF + 4 * 4096 + (W4_HALO ? HBUF + 256 : 0) + (W4_PSYNC ? 16 : 0)) * 4;   // V, epilogue exchange (one 64-pixel x 64-channel plane per output
+constexpr int SMEM_BYTES = (2 * VBUF + 4 * 4096 + HBUF + 256) * 4;   // V, epilogue exchange (one 64-pixel x 64-channel plane per output
                                                                                       // row of the Winograd tiles), raw halo + 1 KB landing zone: 163072
-[[maybe_unused]] constexpr int INV = 1 << 30;            // "outside the image" marker of a row / column offset (operands span < 1 GiB)
 constexpr int OOB = (int)0x80000000u;
 
 struct Wino4Args {
@@ -157,7 +114,7 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int voff, int 
 }
 // the producers' streamed operands (halo, epilogue operands: each byte is read about once) and the output, with a cache-policy field of their own
 __device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, W4_LDPOL));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 __device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -191,15 +148,19 @@ __device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, 
 //               and the raw conv result -> the LDS exchange buffer, one output row of every Winograd tile per round.  Their vector
 //               memory queue holds nothing but U loads (L2 hits): vector memory operations return in order, so a single HBM miss or
 //               store burst in that queue holds up every U fragment queued behind it (measured: 5-6k cycles per tile).
-//   waves 4..7  PRODUCERS -- all other global traffic.  Per 16-channel chunk: the tile's raw halo (340 pixels x 64 B) comes in as six
-//               16-B loads per thread two chunk steps ahead (zero padding and ragged edges are out-of-range buffer offsets) and is
-//               staged in LDS; then one (Winograd tile, channel) item per thread: its 6x6 patch from the staged halo, Bt d B in
-//               registers, nine ds_write_b128 into the V buffer of the next chunk (W4_HALO = 0: 36 dword loads per thread straight
-//               from global memory instead -- 7 % slower: the producers set the pace and vector-memory issue is what they pay most for); and per chunk
-//               one exchange plane of the PREVIOUS tile read back as whole pixels (16 B per lane, 256 B contiguous per pixel),
-//               LeakyReLU / mask / residuals applied, stored.  Their loads miss to HBM and their stores drain while the consumer of the
-//               same SIMD keeps the matrix pipe busy.
-// Barriers per tile: two per chunk (halo staged | V of the next chunk published, this chunk's V free) + one for the exchange buffer.
+//   waves 4..7  PRODUCERS -- all other global traffic.  Per 16-channel chunk step c:
+//                 1. the raw halo of chunk c + 1 (340 pixels x 64 B, requested as six 16-B loads per thread two steps earlier; zero padding and ragged edges
+//                    are out-of-range buffer offsets) goes from registers to LDS;
+//                 2. exchange plane c of the PREVIOUS tile is drained: four 16-B units per thread read back as whole pixels (256 B contiguous per pixel),
+//                    activation / LeakyReLU' mask / residuals applied, stored; then the epilogue operand of plane c + 1 is requested (a whole step ahead);
+//                 3. barrier A (all eight waves; the consumers join it at MFMA group W4_AG without draining their LDS reads);
+//                 4. one (Winograd tile, channel) item per thread: its 6x6 patch from the staged halo, Bt d B in registers (column pass in packed math),
+//                    nine ds_write_b128 into the V buffer of the next chunk; the halo of chunk c + 3 is requested;
+//                 5. chunk barrier B -- except behind the tile's last chunk, where the exchange barrier that follows the consumers' At M A does both jobs.
+//               Round 4 (profiles/r04_logs): steps 2 and 4 used to run in the order 4, 2 behind barrier A, i.e. the drain's LDS round trips, three scalar
+//               branches per unit on the activation form and the wait for a just-requested residual all sat on the path the consumers wait for at B:
+//               184 -> 165 us (no residual) and 218 -> 187 us (residual) per op at B = 32 in one process, results bit-equal.
+// Barriers per tile: two per chunk (A: halo staged | B: V of the next chunk published, this chunk's V free), the last B replaced by the exchange barrier: 8.
 // ACT: the activation as a compile-time form -- 0 none (slope 1), 1 max(v, v * slope) (0 <= slope < 1), 2 the select form (any slope): the run-time choice was
 // three scalar branches per drained 16-B unit on the producers' path.
 template <bool MASK, bool HAS_E, bool HAS_L, int ACT>
@@ -207,9 +168,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const sV = smem;                 // V[2][16 tiles][16 ch][36]
   float* const sX = smem + 2 * VBUF;      // epilogue exchange: [4 rows a][64 pixels][64 channels]
-  float* const sH = sX + 4 * 4096;        // (W4_HALO) raw halo of one chunk: [340 pixels][16 channels], then the landing zone
+  float* const sH = sX + 4 * 4096;        // raw halo of one chunk: [340 pixels][16 channels], then the landing zone
   const int tid = threadIdx.x & 255, lane = tid & 63, w4 = (threadIdx.x >> 6) & 3;
-  const bool producer = W4_SWAP ? threadIdx.x < 256 : threadIdx.x >= 256;
+  const bool producer = threadIdx.x >= 256;
   const int nblk = gridDim.x;
   // a block walks a CONTIGUOUS range of tiles (the next tile's patch rows share pages and two pixel rows with this one's)
   int tile = (int)(((long long)blockIdx.x * p.ntiles) / nblk);
@@ -224,12 +185,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #if W4_CLK
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#if W4_PRIO
-  if ((__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) != (W4_SWAP != 0)) __builtin_amdgcn_s_setprio(W4_PRIO);
-#endif
   if (producer) {
-#if W4_LEAN
-    // ================================================= PRODUCER (instruction-lean form) =========================================
+    // ======================================================= PRODUCER ==========================================================
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int c16 = lane & 15, ptile = 4 * w4 + (lane >> 4), pty = ptile >> 3, ptx = ptile & 7;
     const float* const Ep = MASK ? p.Mk : p.R1;
@@ -267,7 +224,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     f32x4 hv0[6], hv1[6];
     auto halo_load = [&](f32x4 (&hv)[6], __amdgpu_buffer_rsrc_t rs, int chunk) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) hv[i] = bload4s(rs, hx[i], chunk * 64);
+      for (int i = 0; i < 6; ++i) hv[i] = bload4s(rs, (W4_ABL & 512) ? (hx[i] & 0xffff) : hx[i], chunk * 64);   // (512: every load from the image's first 64 KB: cache hits)
     };
     float* hdst[6];
 #pragma unroll
@@ -279,24 +236,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(hdst[i]) = hv[i];
     };
-#if W4_PSYNC
-    // the producers' own meeting point: a counter in LDS that only grows (LDS operations of a wave execute in order, so a wave's add follows its halo stores)
-    unsigned* const pcnt = reinterpret_cast<unsigned*>(sH + HBUF + 256);
-    int psync_target = 0;
-    auto psync = [&]() {
-      psync_target += 4;
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(pcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      for (int it = 0; it < (1 << 16); ++it) {   // bounded: a lost partner ends in wrong results, not in a hang
-        const unsigned v = __hip_atomic_load(pcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((int)__builtin_amdgcn_readfirstlane(v) >= psync_target) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    };
-#endif
     // ---- input transform of one (Winograd tile, channel) item: R[3 r + k] = patch (row r, columns 2 k, 2 k + 1)
     const float* const hR = sH + ((4 * pty) * 34 + 4 * ptx) * 16 + c16;
     f32x2 R[18];
@@ -362,7 +301,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         const bool bad = ragged_w && col0 + dcol[i] >= p.W;
         const int offy = pY[i] + rowoff * (p.y_stride * 4), offe = pE[i] + rowoff * (e_stride * 4);
         oy[i] = bad ? OOB : offy;
-        if (HAS_E) e[i] = bload4s(rsE, bad ? OOB : offe, 0);
+        if (HAS_E) e[i] = bload4s(rsE, (W4_ABL & 1024) ? (offe & 0xffff) : bad ? OOB : offe, 0);   // (1024: epilogue operand from the image's first 64 KB)
       }
     };
     auto drain_plane = [&](int a) {
@@ -388,7 +327,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
           v[i] += e[i];
         }
         if (HAS_L) { const int offl = pL[i] + rowoff * (l_stride * 4); v[i] += bload4s(rsLp, oy[i] == OOB ? OOB : offl, 0); }
-        if (!(W4_ABL & 32) || i == 0) bstore4(rsYp, oy[i], v[i]);
+        if (!(W4_ABL & 32) || i == 0) bstore4(rsYp, (W4_ABL & 256) ? (oy[i] & 0xffff) : oy[i], v[i]);   // (256: every store into the image's first 64 KB)
       }
     };
 
@@ -399,9 +338,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     halo_load(hv0, rsXc, 0);
     halo_load(hv1, rsXc, 1);
     halo_store(hv0);
-#if W4_PSYNC
-    if (tid == 0) *pcnt = 0u;
-#endif
     LDS_BARRIER();   // (A: halo of chunk 0 staged)
     read_raw();
     halo_load(hv0, rsXc, 2);
@@ -432,19 +368,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
           }
         }
         PSTAMP(32 + 8 * c + 0);
-#if W4_PSYNC
-        psync();         // (A, producers only)
-#else
         LDS_BARRIER();   // (A)
-#endif
         PSTAMP(32 + 8 * c + 1);
         read_raw();
         if (c == 1) {   // chunk c + 3 is chunk 0 of the next tile from here on (no next tile: an empty descriptor, every load returns 0)
           rsXn = img_rsrc(p.X, p.x_stride, nimg);
           halo_offsets(ny0, nx0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!W4_LATELOAD && !(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 2);
         if (!(W4_ABL & 2)) transform();
@@ -453,7 +383,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         PSTAMP(32 + 8 * c + 3);
         if (!W4_DRAIN) drain_plane(c);
         __builtin_amdgcn_sched_barrier(0);
-        if (W4_LATELOAD && !(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
+        if (!(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 4);
         if (!(W4_XB && c == 3)) LDS_BARRIER();   // (B)
@@ -471,258 +401,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       tile = next; img = nimg; y0 = ny0; x0 = nx0;
       rsXc = rsXn;
     }
-#else
-    // ======================================================= PRODUCER ==========================================================
-    const int c16 = lane & 15, ptile = 4 * w4 + (lane >> 4), pty = ptile >> 3, ptx = ptile & 7;
-    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes), rsY = make_rsrc(p.Y, p.y_bytes);
-    const __amdgpu_buffer_rsrc_t rsE = make_rsrc(MASK ? p.Mk : p.R1, MASK ? p.mk_bytes : p.r1_bytes), rsL = make_rsrc(MASK ? p.R1 : p.R2, MASK ? p.r1_bytes : p.r2_bytes);
-    const int e_stride = MASK ? p.mk_stride : p.r1_stride, e_choff = MASK ? p.mk_choff : p.r1_choff;
-    const int l_stride = MASK ? p.r1_stride : p.r2_stride, l_choff = MASK ? p.r1_choff : p.r2_choff;
-    auto tile_origin = [&](int t, int& img, int& y0, int& x0) {
-      int txx = t % p.tiles_x; int q = t / p.tiles_x;
-      int tyy = q % p.tiles_y; img = q / p.tiles_y;
-      y0 = tyy * 8; x0 = txx * 32;
-    };
-    // byte offsets of the 6 patch rows and 6 patch columns (sum = element offset; INV in either -> beyond the descriptor's range)
-    int ro[6], co[6];
-    auto patch_offsets = [&](bool valid, int img, int y0, int x0) {
-      if (W4_ABL & 8) { img = blockIdx.x & 7; y0 = 0; x0 = 0; }   // (timing ablation: every tile reads the same few patches -- cache hits only)
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const int yy = y0 + 4 * pty - 1 + r;
-        ro[r] = (valid && (unsigned)yy < (unsigned)p.H) ? ((img * p.H + yy) * p.W) * (p.x_stride * 4) : INV;
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const int xx = x0 + 4 * ptx - 1 + c;
-        co[c] = ((unsigned)xx < (unsigned)p.W) ? xx * (p.x_stride * 4) + (p.x_choff + c16) * 4 : INV;
-      }
-    };
-    // the patch of chunk k lives in raw[k & 1]; it is requested two chunks (~10k cycles) before its transform: a tile's first chunk
-    // is the first touch of its pixels
-    float raw0[36], raw1[36];
-    auto load_raw = [&](float (&raw)[36], int chunk) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r) asm volatile("" : "+v"(ro[r]));   // the 36 sums are formed here, not kept across the tile
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) raw[6 * r + c] = bload1(rsX, ro[r] + co[c], chunk * 64);
-#if W4_PACE
-        // one patch row at a time: the CU's L1 serves the consumers' U stream too, and a burst of 576 line requests (most of them
-        // HBM misses on a tile's first chunks) sits in front of it
-        __builtin_amdgcn_sched_barrier(0);
-        if (r < 5) __builtin_amdgcn_s_sleep(W4_PACE);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-      }
-    };
-    auto transform = [&](float (&raw)[36]) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) bt6(raw[c], raw[6 + c], raw[12 + c], raw[18 + c], raw[24 + c], raw[30 + c]);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) bt6(raw[6 * r], raw[6 * r + 1], raw[6 * r + 2], raw[6 * r + 3], raw[6 * r + 4], raw[6 * r + 5]);
-    };
-    float* const vW = sV + ptile * TS + c16 * 36;
-    auto write_v = [&](float (&raw)[36], int par) {
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        f32x4 v; v.x = raw[4 * q]; v.y = raw[4 * q + 1]; v.z = raw[4 * q + 2]; v.w = raw[4 * q + 3];
-        *reinterpret_cast<f32x4*>(vW + par * VBUF + 4 * q) = v;
-      }
-    };
-    // epilogue reader slots of a round a: (pixel, 16-B unit) = (idx >> 4, idx & 15), idx = tid + 256 i
-    auto reader_pix = [&](int a, int i, int eimg, int ey0, int ex0) -> int {
-      const int px = (tid + 256 * i) >> 4;
-      const int yy = ey0 + 4 * (px >> 5) + a, xx = ex0 + (px & 31);
-      return (yy < p.H && xx < p.W) ? (eimg * p.H + yy) * p.W + xx : -1;
-    };
-
-    int pix[4];
-    f32x4 e[4];
-    auto drain_request = [&](int a, int eimg, int ey0, int ex0) {   // pixel slots of plane a and their first operand (ahead of the patch loads)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        pix[i] = eimg >= 0 ? reader_pix(a, i, eimg, ey0, ex0) : -1;
-        if (HAS_E) e[i] = bload4(rsE, pix[i] >= 0 ? pix[i] * (e_stride * 4) + e_choff * 4 + (tid & 15) * 16 : OOB, 0);
-      }
-    };
-    auto drain_plane = [&](int a) {
-      const float* const xb = sX + a * 4096;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int px = (tid + 256 * i) >> 4, un = tid & 15;
-        f32x4 v = *reinterpret_cast<const f32x4*>(xb + px * 64 + ((un ^ ((px >> 2) & 7)) << 2));
-        if (!(W4_CLRELU && !MASK)) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = v[k] >= 0.f ? v[k] : v[k] * p.slope;
-        }
-        if (MASK) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] *= e[i][k] > 0.f ? 1.f : p.mk_slope;
-        } else if (HAS_E) {
-          v += e[i];
-        }
-        if (HAS_L) v += bload4(rsL, pix[i] >= 0 ? pix[i] * (l_stride * 4) + l_choff * 4 + un * 16 : OOB, 0);
-        if (!(W4_ABL & 32) || i == 0) bstore4(rsY, pix[i] >= 0 ? pix[i] * (p.y_stride * 4) + p.y_choff * 4 + un * 16 : OOB, v);
-      }
-    };
-    int img, y0, x0;
-    int pimg = -1, py0 = 0, px0 = 0;
-    tile_origin(tile, img, y0, x0);
-#if W4_HALO
-    // ---- halo staging: slot i of a thread = (halo pixel, 16-B quarter of the chunk's 64 B) = (idx >> 2, idx & 3), idx = tid + 256 i.
-    // The halo of chunk k waits in hv[k & 1] (requested two chunk steps before its use: a tile's first chunk is the first touch of
-    // its pixels); step k: registers -> LDS, barrier, every thread reads its own 6x6 patch, transform, V.
-    int hx[6];
-    [[maybe_unused]] int hxn[6];
-    auto halo_offsets = [&](int (&hx)[6], bool valid, int img, int y0, int x0) {
-      if (W4_ABL & 8) { img = blockIdx.x & 7; y0 = 0; x0 = 0; }
-      const int base = (((img * p.H + y0 - 1) * p.W + x0 - 1) * p.x_stride + p.x_choff) * 4;   // wave-uniform
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int px = (tid + 256 * i) >> 2, cq = tid & 3;
-        const int r = __mul24(px, 1928) >> 16;   // px / 34 for px < 384
-        const int c = px - r * 34;
-        const int yy = y0 + r - 1, xx = x0 + c - 1;
-        const bool ok = valid && px < HPIX && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        hx[i] = ok ? base + __mul24(__mul24(r, p.W) + c, p.x_stride * 4) + cq * 16 : OOB;
-      }
-    };
-    const __amdgpu_buffer_rsrc_t rsXh = make_rsrc(p.X, p.x_bytes);
-    f32x4 hv0[6], hv1[6];
-    auto halo_load = [&](f32x4 (&hv)[6], int chunk) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) hv[i] = bload4(rsXh, hx[i], chunk * 64);
-    };
-    auto halo_store = [&](f32x4 (&hv)[6]) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int px = (tid + 256 * i) >> 2, cq = tid & 3;
-        // W4_SWZ: pixel px lands in the slot of px ^ ((column >> 2) & 1): neighbours (px, px ^ 1) share a row and (column >> 2), so this is a permutation of pairs
-        const int pxs = W4_SWZ ? px ^ (((px - (__mul24(px, 1928) >> 16) * 34) >> 2) & 1) : px;
-        float* dst = (i < 5 || px < HPIX) ? sH + pxs * 16 + cq * 4 : sH + HBUF + (tid & 63) * 4;   // slots 340..383: landing zone
-        *reinterpret_cast<f32x4*>(dst) = hv[i];
-      }
-    };
-    const float* const hR = sH + ((4 * pty) * 34 + 4 * ptx) * 16 + c16;
-    auto read_raw = [&](float (&raw)[36]) {
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) raw[6 * r + c] = W4_SWZ ? hR[((r * 34 + c) ^ ((ptx + (c >> 2)) & 1)) * 16] : hR[(r * 34 + c) * 16];
-    };
-    halo_offsets(hx, true, img, y0, x0);
-    halo_load(hv0, 0);
-    halo_load(hv1, 1);
-    halo_store(hv0);
-    LDS_BARRIER();   // (A: halo of chunk 0 staged)
-    read_raw(raw0);
-    halo_load(hv0, 2);
-    transform(raw0);
-    write_v(raw0, 0);
-    LDS_BARRIER();   // (B0)
-#else
-    patch_offsets(true, img, y0, x0);
-    load_raw(raw0, 0);
-    transform(raw0);
-    write_v(raw0, 0);
-    load_raw(raw1, 1);
-    load_raw(raw0, 2);
-    LDS_BARRIER();   // (B0)
-#endif
-    while (true) {
-      const int next = tile + 1;
-      const bool has_next = next < tile_end;
-      int nimg = 0, ny0 = 0, nx0 = 0;
-      if (has_next) tile_origin(next, nimg, ny0, nx0);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        // chunk c + 1 (chunk 0 of the next tile when c == 3): transform, V -> the other buffer; then request chunk c + 3 into its registers
-#if W4_HALO
-        {   // chunk c + 1 (chunk 0 of the next tile when c == 3): halo registers -> LDS | patch -> transform -> V of the other parity
-          f32x4 (&hv)[6] = ((c + 1) & 1) ? hv1 : hv0;
-          halo_store(hv);
-          drain_request(c, pimg, py0, px0);
-          __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(32 + 8 * c + 0);
-          LDS_BARRIER();   // (A)
-          PSTAMP(32 + 8 * c + 1);
-          read_raw(raw0);
-#if W4_BURST
-          if (c == 1) {   // chunk c + 3 is chunk 0 of the next tile from here on (its offsets were formed in step 0's burst)
-#pragma unroll
-            for (int i = 0; i < 6; ++i) hx[i] = hxn[i];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (!(W4_ABL & 1)) halo_load(hv, (c + 3) & 3);
-          __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(32 + 8 * c + 2);
-          drain_plane(c);
-          __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(32 + 8 * c + 4);
-          LDS_BARRIER();   // (B1: the consumers have issued this chunk's last MFMA; the FMA lanes are the producers' until B)
-          PSTAMP(32 + 8 * c + 5);
-          if (!(W4_ABL & 2)) transform(raw0);
-          if (!(W4_ABL & 4)) write_v(raw0, (c + 1) & 1);
-          if (c == 0) halo_offsets(hxn, has_next, nimg, ny0, nx0);
-          __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(32 + 8 * c + 3);
-          LDS_BARRIER();   // (B)
-          PSTAMP(32 + 8 * c + 6);
-          continue;
-#endif
-          if (c == 1) halo_offsets(hx, has_next, nimg, ny0, nx0);   // chunk c + 3 is chunk 0 of the next tile from here on
-          __builtin_amdgcn_sched_barrier(0);
-          if (!(W4_ABL & 1)) halo_load(hv, (c + 3) & 3);
-          __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(32 + 8 * c + 2);
-          if (!(W4_ABL & 2)) transform(raw0);
-          if (!(W4_ABL & 4)) write_v(raw0, (c + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(32 + 8 * c + 3);
-          drain_plane(c);
-          __builtin_amdgcn_sched_barrier(0);
-          PSTAMP(32 + 8 * c + 4);
-          LDS_BARRIER();   // (B)
-          PSTAMP(32 + 8 * c + 5);
-          continue;
-        }
-#endif
-        float (&raw)[36] = ((c + 1) & 1) ? raw1 : raw0;
-        drain_request(c, pimg, py0, px0);
-#ifdef LFSR_CONV_DIAG
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (so that segment 24 is the wait for the patch / operand loads)
-#endif
-        PSTAMP(32 + 8 * c + 0);
-        if (!(W4_ABL & 2)) transform(raw);
-        __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(32 + 8 * c + 1);
-        if (!(W4_ABL & 4)) write_v(raw, (c + 1) & 1);
-        if (c == 1) patch_offsets(has_next, nimg, ny0, nx0);
-        __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(32 + 8 * c + 2);
-        if (!(W4_ABL & 1) && !((W4_ABL & 64) && c == 3) && !((W4_ABL & 128) && c == 1)) load_raw(raw, (c + 3) & 3);
-        __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(32 + 8 * c + 3);
-        // output row c of the PREVIOUS tile's Winograd tiles (pimg < 0: none): exchange plane c -> whole pixels, 16 B per lane
-        drain_plane(c);
-        __builtin_amdgcn_sched_barrier(0);
-        PSTAMP(32 + 8 * c + 4);
-        LDS_BARRIER();
-        PSTAMP(32 + 8 * c + 5);
-      }
-      LDS_BARRIER();   // this tile's results are in the exchange planes
-      PSTAMP(62);
-      pimg = img; py0 = y0; px0 = x0;
-      if (!has_next) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { drain_request(a, pimg, py0, px0); drain_plane(a); }
-        break;
-      }
-      tile = next; img = nimg; y0 = ny0; x0 = nx0;
-    }
-#endif   // W4_LEAN
   } else {
     // ======================================================= CONSUMER ==========================================================
     const int ctile = lane & 15, kk = lane >> 4, cty = ctile >> 3, ctx = ctile & 7;
@@ -736,7 +414,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, uoff, ((i / 9) * 36 + (i % 9)) * 1024);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[36];
-    if (W4_HALO) LDS_BARRIER();   // (A of the prologue)
+    LDS_BARRIER();   // (A of the prologue)
     LDS_BARRIER();   // (B0)
     STAMP(9);
     while (true) {
@@ -757,32 +435,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
             if (g + VA < 36) Vq[(g + VA) % W4_VRING] = *reinterpret_cast<const f32x4*>(vR + par * VBUF + ((g + VA) / 9) * 144 + ((g + VA) % 9) * 4);
             const f32x4 u = U[t % W4_URING], v = Vq[g % W4_VRING];
             const bool first = (c == 0 && s4 == 0);
-#if W4_MFMA4
-            // D block (g, c) [i][j] += A block (g, k) [i] * B block (k, c) [j]:  A lane 16 g + 4 k + i = U[ch 4 g + i][k] (the pack's lane order),
-            // B lane 16 k + tile and D (vgpr i, lane 16 g + tile) exactly as the 16x16x4 form has them
-            if (first) { acc[4 * q + 0] = zero4; acc[4 * q + 1] = zero4; acc[4 * q + 2] = zero4; acc[4 * q + 3] = zero4; }
-#define W4_K(KK) \
-            acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(u.x, v.x, acc[4 * q + 0], 2, KK, 4 + KK); \
-            acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(u.y, v.y, acc[4 * q + 1], 2, KK, 4 + KK); \
-            acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_4x4x1f32(u.z, v.z, acc[4 * q + 2], 2, KK, 4 + KK); \
-            acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(u.w, v.w, acc[4 * q + 3], 2, KK, 4 + KK);
-            W4_K(0) W4_K(1) W4_K(2) W4_K(3)
-#undef W4_K
-#else
             acc[4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v.x, first ? zero4 : acc[4 * q + 0], 0, 0, 0);
             acc[4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v.y, first ? zero4 : acc[4 * q + 1], 0, 0, 0);
             acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[4 * q + 2], 0, 0, 0);
             acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[4 * q + 3], 0, 0, 0);
-#endif
             const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
             if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
             __builtin_amdgcn_sched_barrier(0);       // (keeps every LDS read two groups ahead of its use)
-            if (W4_HALO && !W4_PSYNC && g == (W4_LEAN ? W4_AG : 3)) { STAMP(24 + c); if (W4_ANW) BARRIER_NOWAIT(); else LDS_BARRIER(); STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
+            if (g == W4_AG) { if (W4_STAMP_A) STAMP(24 + c); if (W4_ANW) BARRIER_NOWAIT(); else LDS_BARRIER(); if (W4_STAMP_A) STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
           }
         }
         STAMP(c);
-        if (W4_BURST) { LDS_BARRIER(); STAMP(10 + c); }   // (B1) the producers' transform burst runs between here and B
-        if (!(W4_XB && W4_LEAN && c == 3)) LDS_BARRIER();   // V of the next chunk published; everyone is done reading this chunk's
+        if (!(W4_XB && c == 3)) LDS_BARRIER();   // V of the next chunk published; everyone is done reading this chunk's
         STAMP(16 + c);
       }
       // At M A in registers; one output row a of every Winograd tile per round -> exchange buffer
@@ -795,10 +459,6 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           f32x4 v = acc[6 * a + b];
-          if (W4_CLRELU && !MASK) {   // the forward activation here: the matrix pipe idles during At M A anyway, and the producers' issue slots are the scarce resource
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = p.slope <= 1.f ? fmaxf(v[k], v[k] * p.slope) : (v[k] >= 0.f ? v[k] : v[k] * p.slope);
-          }
           *reinterpret_cast<f32x4*>(xb + xw + b * 64) = v;
         }
       }
@@ -816,9 +476,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   }
 #endif
 #ifdef LFSR_CONV_DIAG
-  if (dbgbuf && threadIdx.x == (W4_SWAP ? 256 : 0))
+  if (dbgbuf && threadIdx.x == 0)
     for (int k = 0; k < 32; ++k) dbgbuf[blockIdx.x * 64 + k] = (float)seg[k];
-  if (dbgbuf && threadIdx.x == (W4_SWAP ? 0 : 256))
+  if (dbgbuf && threadIdx.x == 256)
     for (int k = 32; k < 64; ++k) dbgbuf[blockIdx.x * 64 + k] = (float)seg[k];
 #endif
 }
@@ -839,7 +499,7 @@ __device__ __forceinline__ void emit_wino4(const double (&g)[3][3], int n, int k
     for (int b = 0; b < 6; ++b) {
       const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
       const int pp = a * 6 + b;
-      const int ln = W4_MFMA4 ? (m >> 2) * 16 + kq * 4 + (m & 3) : kq * 16 + m;
+      const int ln = kq * 16 + m;
       out[((((s * 4 + nsl) * 9 + (pp >> 2)) * 64 + ln) << 2) + (pp & 3)] = (float)u;
     }
 }
