@@ -60,6 +60,8 @@ def parse():
                     help="default: the GEMMs that have an exact-three-term-bf16 form run it (EPI branch, fuse.0, the transformers' linears / FFN / tail); "
                          "f32: every GEMM on fp32 MFMA (lfsr_set_arithmetic)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the configs[2] / [3] / [4] lines (EPIT, training step, LFT scene) of the default run")
+    ap.add_argument("--scene-size", type=int, default=128, help="--workload lft: the scene is 5x5 views of SIZE x SIZE (128 -> 64 patches, the default; 512 -> 1024 "
+                    "patches, i.e. 128 per GPU at 8 GPUs: the strong-scaling leg with every GPU's convs at full tile rounds)")
     ap.add_argument("--batch", type=int, default=0, help="patches per GPU (default: 32 infer, 8 train / epit / lft)")
     ap.add_argument("--workload", choices=["infer", "train", "epit", "lft"], default="infer",
                     help="infer = configs[1] (headline, default); train = configs[3]: DistgSSR x4 fp32 train step, batch 8 per GPU, RCCL bucket "
@@ -228,7 +230,8 @@ def init_rank(args):
 
 
 def timed_loop(step, args, dev, dist):
-    """W warm-ups, then exactly K steps bracketed by barrier + synchronize; returns the max-over-ranks seconds and the last result."""
+    """W warm-ups, then exactly K steps bracketed by barrier + synchronize; returns the max-over-ranks seconds, the last result and (N > 1) what the
+    ranks themselves saw of the job: the backend, the number of ranks a sum of ones over that backend returns, every rank's own step time and device."""
     import torch
     r = None
     for _ in range(args.warmup):
@@ -245,11 +248,29 @@ def timed_loop(step, args, dev, dist):
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    seen = None
     if dist is not None:
+        mine = el
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    return el, r
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)                       # every rank that takes part in the collective adds one
+        backend = dist.get_backend()
+        xdev = dev if backend == "nccl" else torch.device("cpu")          # (gloo gathers host tensors only)
+        prop = torch.cuda.get_device_properties(dev)
+        uid = str(getattr(prop, "uuid", ""))[:40]
+        rec = torch.zeros(3 + 40, dtype=torch.float64, device=xdev)
+        rec[0], rec[1], rec[2] = mine / max(args.steps, 1) * 1e3, float(dev.index), float(os.getpid())
+        if uid:
+            rec[3:3 + len(uid)] = torch.tensor([float(ord(ch)) for ch in uid], dtype=torch.float64)
+        allrec = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
+        dist.all_gather(allrec, rec)
+        seen = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "ranks_seen": int(round(float(ones.item()))),
+                "per_rank_ms_per_step": [float(a[0]) for a in allrec],
+                "per_rank_device": [{"cuda_index": int(a[1]), "pid": int(a[2]), "name": prop.name,
+                                     "uuid": "".join(chr(int(v)) for v in a[3:].tolist() if v > 0) or None} for a in allrec]}
+    return el, r, seen
 
 
 def finish(dist):
@@ -258,11 +279,29 @@ def finish(dist):
         dist.destroy_process_group()
 
 
-def base_line(args, world, el, patches_per_step, metric, workload, extra_cfg):
+def base_line(args, world, el, patches_per_step, metric, workload, extra_cfg, seen=None):
+    line = _base_line(args, world, el, patches_per_step, metric, workload, extra_cfg)
+    if seen is not None:      # N > 1: what the ranks saw -- the collective's own count of participants, every rank's clock and device
+        line["multi_gpu"] = seen
+    return line
+
+
+def _base_line(args, world, el, patches_per_step, metric, workload, extra_cfg):
     return {"metric": metric, "value": world * patches_per_step * args.steps / el, "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": dict({"workload": workload, "batch_per_gpu": patches_per_step}, **extra_cfg)}
+
+
+def train_arithmetic(all_f32):
+    """(dtype, per-operator arithmetic) of the DistgSSR training step under the library's arithmetic selection (lfsr_set_arithmetic): by default the EPI branch's
+    forward, fuse.0's forward and fuse.0's data gradient run with fp32 operands carried as three exact bf16 terms; everything else is fp32 MFMA."""
+    if all_f32:
+        return "f32", {k: "f32" for k in ("conv3x3", "conv3x3_dgrad", "conv3x3_wgrad", "epiconv", "fuse.0", "fuse.0_dgrad", "angconv", "branch gradients", "head")}
+    return ("f32 (EPI branch forward, fuse.0 forward and fuse.0 data gradient: fp32 operands as three exact bf16 terms on the bf16 MFMA pipe, fp32 accumulation; "
+            "3x3 convs and their gradients, angular branch, the branches' gradients, init, head: fp32 MFMA)",
+            {"conv3x3": "f32", "conv3x3_dgrad": "f32", "conv3x3_wgrad": "f32", "epiconv": "bf16x3", "fuse.0": "bf16x3", "fuse.0_dgrad": "bf16x3", "angconv": "f32",
+             "branch gradients": "f32", "head": "f32"})
 
 
 def bench_train(args, rank, world, dev, dist):
@@ -288,11 +327,12 @@ def bench_train(args, rank, world, dev, dist):
     opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4)
     x = torch.from_numpy(synth_input((Bt, 1, A * H, A * W), seed=1 + rank)).to(dev)
     y = torch.from_numpy(synth_input((Bt, 1, A * H * S, A * W * S), seed=100 + rank)).to(dev)
-    el, (loss, _) = timed_loop(lambda: train_step(net, crit, opt, x, y), args, dev, dist)
+    el, (loss, _), seen = timed_loop(lambda: train_step(net, crit, opt, x, y), args, dev, dist)
     if rank == 0:
         line = base_line(args, world, el, Bt, "5x5 x4-SR LF patches/sec (32^2->128^2), DistgSSR training step (fwd+bwd+allreduce+AdamW)",
                          "configs[3]: DistgSSR 5x5 x4 training, batch 8 per GPU, data-parallel, one RCCL all-reduce of the flat gradient bucket",
-                         {"parallelism": f"dp{world}"})
+                         {"parallelism": f"dp{world}"}, seen)
+        line["dtype"], line["config"]["gemm_arithmetic"] = train_arithmetic(args.arithmetic == "f32")
         line["loss"] = float(loss)
         line["model_tflops"] = 3 * FLOP_PER_PATCH["distgssr"] * world * Bt * args.steps / el / 1e12
         print(json.dumps(line), flush=True)
@@ -314,21 +354,24 @@ def bench_model(args, rank, world, dev, dist):
     if name == "epit":
         Bm = args.batch or 8
         x = torch.from_numpy(synth_input((Bm, 1, A * H, A * W), seed=1 + rank)).to(dev)
-        el, y = timed_loop(lambda: rt.forward(x), args, dev, dist)
+        el, y, seen = timed_loop(lambda: rt.forward(x), args, dev, dist)
         per_step, wl = Bm, f"configs[2]: EPIT 5x5 x4 inference, batch {Bm} patches per GPU"
         par = f"patch-sharded x{world}, no data-path collective"
     else:
         from lfsr_amd.dispatch import sr_scene
-        scene = torch.from_numpy(synth_input((A * 128, A * 128), seed=3)).to(dev)      # 5x5x128x128 -> 64 patches -> (5,5,512,512)
-        el, y = timed_loop(lambda: sr_scene(lambda t, info=None: rt.forward(t), scene, A, S, minibatch=args.batch or 32, dst=0), args, dev, dist)
-        per_step, wl = 64.0 / world, "configs[4]: LFT 5x5 x4 full-scene inference (5x5x128x128 -> 64 patches via LFdivide / LFintegrate)"
-        par = (f"64 patches sharded over {world} rank(s); each rank crops its SR patches to the tiles LFintegrate keeps, one gather of the tiles "
-               "(26 MB per scene in total) to rank 0, which places them")
+        sz = args.scene_size
+        scene = torch.from_numpy(synth_input((A * sz, A * sz), seed=3)).to(dev)      # 5x5x128x128 -> 64 patches -> (5,5,512,512); 5x5x512x512 -> 1024 patches
+        n_patches = int(capi.lf_divide(scene, A, 32, 16).shape[:2].numel())
+        el, y, seen = timed_loop(lambda: sr_scene(lambda t, info=None: rt.forward(t), scene, A, S, minibatch=args.batch or 32, dst=0), args, dev, dist)
+        per_step, wl = float(n_patches) / world, f"configs[4]: LFT 5x5 x4 full-scene inference (5x5x{sz}x{sz} -> {n_patches} patches via LFdivide / LFintegrate)"
+        par = (f"{n_patches} patches sharded over {world} rank(s); each rank crops its SR patches to the tiles LFintegrate keeps, one gather of the tiles "
+               f"({n_patches * A * A * 64 * 64 * 4 / 1e6:.0f} MB per scene in total) to rank 0, which places them")
     if rank == 0:
         assert torch.isfinite(y).all()
-        line = base_line(args, world, el, per_step, f"5x5 x4-SR LF patches/sec (32^2->128^2), {key} inference", wl, {"parallelism": par})
+        line = base_line(args, world, el, per_step, f"5x5 x4-SR LF patches/sec (32^2->128^2), {key} inference", wl, {"parallelism": par}, seen)
         if name == "lft":
             line["scaling"] = "strong"
+            line["config"]["scene"] = {"size": [A, A, args.scene_size, args.scene_size], "patches": n_patches}
         line["model_tflops_windowed"] = FLOP_PER_PATCH[name] * line["value"] / 1e12
         # the arithmetic the transformer GEMMs run in (rowgemm_b3.hip / ffn_b3.hip / up_tail.hip): fp32 operands split EXACTLY into three bf16 terms, six
         # products on the bf16 MFMA pipe, fp32 accumulation -- error against fp64 below the fp32-MFMA kernels' (tools/b3_accuracy.py); LFSR_ROWGEMM=f32
@@ -422,7 +465,7 @@ def other_workloads(dev, budget_steps=(20, 10, 8)):
     # ---- configs[2] EPIT B = 8 and configs[4] LFT scene: both arithmetic selections (read when the runtime is built and at every launch) ----
     for name, key, steps in (("epit", "EPIT", budget_steps[0]), ("lft", "LFT", budget_steps[2])):
         sd = synth_state_dict([(k, tuple(sh)) for k, sh in meta_all[key]["full"]["spec"]], seed=0)
-        lines = {}
+        lines, b1 = {}, {}
         for arith in ("bf16x3", "f32"):
             capi.set_arithmetic(capi.ARITH_F32 if arith == "f32" else capi.ARITH_DEFAULT)
             rt = capi.ModelRuntime(name, A, S, 5 if name == "epit" else 4, 64)
@@ -430,6 +473,9 @@ def other_workloads(dev, budget_steps=(20, 10, 8)):
             if name == "epit":
                 x = torch.from_numpy(synth_input((8, 1, A * H, A * W), seed=1)).to(dev)
                 step, per_step, npix = (lambda: rt.forward(x)), 8, 8 * A * A * H * W
+                x1 = x[:1].contiguous()           # B in {1, 8}
+                sec1 = timed(lambda: rt.forward(x1), 3, steps)
+                b1[arith] = {"value": 1 / sec1, "ms_per_step": sec1 * 1e3}
             else:
                 from lfsr_amd.dispatch import sr_scene
                 scene = torch.from_numpy(synth_input((A * 128, A * 128), seed=3)).to(dev)
@@ -446,7 +492,11 @@ def other_workloads(dev, budget_steps=(20, 10, 8)):
                     "gemm_arithmetic": "bf16x3", "dominant_kernel": b3["dominant"],
                     "all_fp32_mfma": {"value": f32["value"], "ms_per_step": f32["ms_per_step"], "dtype": "f32", "gemm_arithmetic": "f32", "dominant_kernel": f32["dominant"]},
                     "model_tflops_windowed": FLOP_PER_PATCH[name] * b3["value"] / 1e12})
-    # ---- configs[3] DistgSSR training step, B = 8 (fp32 MFMA only) ----
+        if name == "epit":
+            out.append({"config": "configs[2]: EPIT 5x5 x4 inference, batch 1 patch, 1 GPU (latency point)", "value": b1["bf16x3"]["value"], "unit": "patches/s",
+                        "ms_per_step": b1["bf16x3"]["ms_per_step"], "steps": steps, "warmup": 3, "dtype": out[-1]["dtype"], "gemm_arithmetic": "bf16x3",
+                        "all_fp32_mfma": dict(b1["f32"], dtype="f32", gemm_arithmetic="f32")})
+    # ---- configs[3] DistgSSR training step, B = 8: default arithmetic (EPI branch, fuse.0 and fuse.0's data gradient on the three-term bf16 form) and all fp32 MFMA ----
     sys.path.insert(0, capi._HERE)
     M = importlib.import_module("model.SR.DistgSSR")
     sys.path.remove(capi._HERE)
@@ -461,9 +511,16 @@ def other_workloads(dev, budget_steps=(20, 10, 8)):
     y = torch.from_numpy(synth_input((8, 1, A * H * S, A * W * S), seed=100)).to(dev)
     step = lambda: train_step(net, crit, opt, x, y)
     sec = timed(step, 3, budget_steps[1])
+    dom = dominant(step, 8 * A * A * H * W, True)
+    capi.set_arithmetic(capi.ARITH_F32)
+    sec_f32 = timed(step, 2, budget_steps[1])
+    capi.set_arithmetic(capi.ARITH_DEFAULT)
+    dtype, arith = train_arithmetic(False)
     out.append({"config": "configs[3]: DistgSSR 5x5 x4 training step (fwd + bwd + clip + AdamW; the RCCL bucket all-reduce is a no-op at N = 1), batch 8, 1 GPU",
-                "value": 8 / sec, "unit": "patches/s", "ms_per_step": sec * 1e3, "steps": budget_steps[1], "warmup": 3, "dtype": "f32", "gemm_arithmetic": "f32",
-                "dominant_kernel": dominant(step, 8 * A * A * H * W, True), "model_tflops": 3 * FLOP_PER_PATCH["distgssr"] * 8 / sec / 1e12})
+                "value": 8 / sec, "unit": "patches/s", "ms_per_step": sec * 1e3, "steps": budget_steps[1], "warmup": 3, "dtype": dtype, "gemm_arithmetic": arith,
+                "dominant_kernel": dom, "model_tflops": 3 * FLOP_PER_PATCH["distgssr"] * 8 / sec / 1e12,
+                "all_fp32_mfma": {"value": 8 / sec_f32, "ms_per_step": sec_f32 * 1e3, "dtype": "f32", "gemm_arithmetic": "f32",
+                                  "selection": "lfsr_set_arithmetic(LFSR_ARITH_F32), same process, same weights, timed right after"}})
     del net, opt
     torch.cuda.empty_cache()
     return out
@@ -516,7 +573,7 @@ def bench_infer(args, rank, world, dev, dist):
     # live instrumentation inside the timed region: hipEvents on the launch stream around every 4th 3x3 conv op (the roofline
     # kernel; 53 ops per forward, so every layer is sampled once in four steps) and nothing else
     rt.profile(3)
-    el, y = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
+    el, y, seen = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
     prof = rt.profile_read()
     # the same timed loop with every GEMM of the forward on fp32 MFMA (lfsr_set_arithmetic(LFSR_ARITH_F32): the F(2,5) fp32 kernel of the EPI branch, fuse.0 on the
     # fp32 row-GEMM): printed beside the headline whenever the headline uses the exact three-term bf16 form for those two operators
@@ -528,7 +585,7 @@ def bench_infer(args, rank, world, dev, dist):
         capi.set_arithmetic(capi.ARITH_F32)
         for _ in range(2):
             rt.forward(x)
-        el_f32, _ = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
+        el_f32, _, _ = timed_loop(lambda: rt.forward(x), argparse.Namespace(warmup=0, steps=args.steps), dev, dist)
         capi.set_arithmetic(capi.ARITH_DEFAULT)
         rt.forward(x)
     rt.profile(1)
@@ -568,7 +625,7 @@ def bench_infer(args, rank, world, dev, dist):
         line = base_line(args, world, el, B, "5x5 x4-SR LF patches/sec (32^2->128^2), DistgSSR inference",
                          f"configs[1]: DistgSSR 5x5 x4 inference, batch {B} patches per GPU (5x5 views of 32x32 -> 128x128)",
                          {"parallelism": f"patch-sharded x{world}, no data-path collective",
-                          "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"})
+                          "weights": "synthetic U(-1/sqrt(fan_in), 1/sqrt(fan_in)), numpy PCG64 seed 0"}, seen)
         if b3_ops:
             line["dtype"] = ("f32 (EPI branch stage 1 / 2 and fuse.0: fp32 operands as three exact bf16 terms on the bf16 MFMA pipe, six products, fp32 accumulation -- "
                              "error against fp64 not above the fp32-MFMA kernels', tests/test_gpu_b3_accuracy.py; 3x3 convs, angular branch, init, head: fp32 MFMA)")

@@ -335,6 +335,24 @@ def pack_conv_weight(w, perm=0, ch=0):
 
 
 # ---------------------------------------------------------------------------------------------------
+# batch limit of one launch sequence
+# ---------------------------------------------------------------------------------------------------
+
+def max_patches_per_launch(A, h, w, widest_row_floats, limit=1 << 31):
+    """The kernels address their operands with 32-bit BYTE offsets (buffer descriptors: an out-of-range offset is a dropped access), so every activation tensor of one
+    forward must stay below 2 GiB -- 1 GiB for DistgSSR, whose F(4x4,3x3) conv kernel keeps one more bit for its "outside the image" offsets: B * A^2 * h * w pixels x the
+    widest row (DistgSSR: the 144-channel concat buffer, counted as 160; EPIT / LFT: the 256-float q | k rows).
+    The C entry points return LFSR_E_ARG beyond that; the runtimes below split a larger batch into equal launches instead (patches are independent and the path is
+    batch-invariant bit for bit -- tests/test_gpu_distgssr.py::test_batch32_equals_single_patches -- so the split changes no value)."""
+    per_patch = A * A * h * w * widest_row_floats * 4
+    return max(1, (limit - 1) // per_patch)
+
+
+def _forward_in_chunks(fwd, x, nmax):
+    return torch.cat([fwd(x[i:i + nmax]) for i in range(0, x.shape[0], nmax)], 0)
+
+
+# ---------------------------------------------------------------------------------------------------
 # DistgSSR whole-model runtime
 # ---------------------------------------------------------------------------------------------------
 
@@ -476,6 +494,8 @@ class DistgSSRRuntime:
             raise LfsrError("DistgSSR HIP path computes in fp32; got " + str(x.dtype))
         h, w = Hh // self.A, Ww // self.A
         x = x.contiguous()
+        if taps is None and B > max_patches_per_launch(self.A, h, w, 160, 1 << 30):
+            return _forward_in_chunks(self.forward, x, max_patches_per_launch(self.A, h, w, 160, 1 << 30))
         out = torch.empty((B, 1, Hh * self.scale, Ww * self.scale), dtype=torch.float32, device=x.device)
         ws = self._workspace(B, h, w, x.device)
         if taps is None:
@@ -620,6 +640,8 @@ class ModelRuntime:
             raise LfsrError(f"{self.name} HIP path computes in fp32; got {x.dtype}")
         h, w = Hh // self.A, Ww // self.A
         x = x.contiguous()
+        if B > max_patches_per_launch(self.A, h, w, 256):
+            return _forward_in_chunks(self.forward, x, max_patches_per_launch(self.A, h, w, 256))
         out = torch.empty((B, 1, Hh * self.scale, Ww * self.scale), dtype=torch.float32, device=x.device)
         key = (B, h, w, x.device)
         if key not in self.ws:

@@ -469,8 +469,6 @@ static int conv3_sel_mask(const char* sel) {
   if (sel[0] == 'h' || sel[0] == 'g') return 0;                              // direct kernels: the direct pack only
   if (sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o') {
     if (sel[4] == '2') return LFSR_W_WINO2;
-    if (sel[4] == '4' && sel[5] == 's') return LFSR_W_WINO4S | LFSR_W_WINO4;   // (+ the kernel an uncovered geometry falls back to)
-    if (sel[4] == '4' && sel[5] == 'b') return LFSR_W_WINO4B | LFSR_W_WINO4;
   }
   return LFSR_W_WINO4;
 }
@@ -489,8 +487,6 @@ int lfsr_pack_wino_m(const float* direct_packed, float* out, int mask, hipStream
     LFSR_CHECK_LAUNCH();
   }
   if (!rc && (mask & LFSR_W_WINO4)) rc = lfsr_pack_wino4(direct_packed, out + LFSR_CONV3_WINO2_FLOATS, st);
-  if (!rc && (mask & LFSR_W_WINO4S)) rc = lfsr_pack_wino4s(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, st);
-  if (!rc && (mask & LFSR_W_WINO4B)) rc = lfsr_pack_wino4b(direct_packed, out + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS, st);
   return rc;
 }
 
@@ -501,19 +497,9 @@ int lfsr_conv3x3_wino_launch(const float* x, int x_stride, int x_choff, const fl
                              const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
                              const float* mk, int mk_stride, int mk_choff, float mk_slope,
                              int n_img, int h, int w, float slope, const char* sel, hipStream_t st) {
-  {   // F(4x4,3x3): the symmetric-wave kernel (conv3x3_wino4s.hip, LFSR_CONV3X3=wino4s) or the specialised-wave one (conv3x3_wino4.hip);
+  {   // F(4x4,3x3), the default (conv3x3_wino4.hip);
       // LFSR_CONV3X3=wino2 keeps this file's F(2x2,3x3) kernel (A/B runs), as do operands the F(4x4) launchers do not cover
     const bool is_w = sel && sel[0] == 'w' && sel[1] == 'i' && sel[2] == 'n' && sel[3] == 'o';
-    if (is_w && sel[4] == '4' && sel[5] == 'b') {
-      const int rc = lfsr_conv3x3_wino4b_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS, y, y_stride, y_choff,
-                                                r1, r1_stride, r1_choff, r2, r2_stride, r2_choff, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);
-      if (rc != LFSR_E_ARG) return rc;
-    }
-    if (is_w && sel[4] == '4' && sel[5] == 's') {
-      const int rc = lfsr_conv3x3_wino4s_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS, y, y_stride, y_choff,
-                                                r1, r1_stride, r1_choff, r2, r2_stride, r2_choff, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);
-      if (rc != LFSR_E_ARG) return rc;
-    }
     if (!(is_w && sel[4] == '2')) {
       const int rc = lfsr_conv3x3_wino4_launch(x, x_stride, x_choff, w_wino + LFSR_CONV3_WINO2_FLOATS, y, y_stride, y_choff, r1, r1_stride, r1_choff,
                                                r2, r2_stride, r2_choff, mk, mk_stride, mk_choff, mk_slope, n_img, h, w, slope, st);

@@ -39,7 +39,7 @@ struct lfsr_distgssr {
   size_t table_cap = 0;
   // backward: the weight gradient of a 3x3 layer runs on a side stream beside the layer's data gradient (both read the same dY); created on first use
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr, ev_w = nullptr, ev_red[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_a = nullptr, ev_b = nullptr;
   bool profiling = false;
   struct Ev { int cls; hipEvent_t a, b; };
   bool profile_all = true;
@@ -115,8 +115,6 @@ void lfsr_distgssr_destroy(lfsr_distgssr* c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
-  if (c->ev_w) (void)hipEventDestroy(c->ev_w);
-  for (int i = 0; i < 2; ++i) if (c->ev_red[i]) (void)hipEventDestroy(c->ev_red[i]);
   if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
@@ -273,7 +271,7 @@ int lfsr_distgssr_forward_taps(lfsr_distgssr* c, const float* x, float* out, int
   size_t off[8], tot;
   ws_layout(c, B, h, w, off, &tot);
   if (workspace_bytes < tot * sizeof(float)) return LFSR_E_WS;
-  if ((long long)B * c->A * c->A * h * w >= (1LL << 31) / 144) return LFSR_E_ARG;  // pixel*stride must fit the kernels' index math
+  if ((long long)B * c->A * c->A * h * w * 160 * 4 >= (1LL << 30)) return LFSR_E_ARG;  // every activation tensor < 1 GiB (the F(4x4) conv kernel's offset range; 32-bit byte offsets everywhere): callers split the batch (capi.py)
   float* ws = (float*)workspace;
   float* pool[4] = {ws + off[0], ws + off[1], ws + off[2], ws + off[3]};
   float* T = ws + off[4];
@@ -363,7 +361,7 @@ struct TrainWs {
   float *F0, *D;
   std::vector<float*> S1, CAT, A16, EH, EV, FZ, OUT, GOUT;
   // backward scratch
-  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *dE32V, *G16, *XG9, *P[4], *PA, *PW[2], *small;   // PA: partial slabs of the angular branch (its own: it may run beside the epipolar one)
+  float *g[4], *dF, *dS1, *dCAT, *dA16, *dE32, *dE32V, *G16, *XG9, *P[4], *PA, *small;   // PA: partial slabs of the angular branch (its own: it may run beside the epipolar one)
   size_t pfloats;
   size_t total;
 };
@@ -404,7 +402,6 @@ void train_layout(const lfsr_distgssr* c, int B, int h, int w, float* base, Trai
   t.pfloats = max_partial_floats(c, B, h, w);
   for (int i = 0; i < 4; ++i) t.P[i] = take(t.pfloats);
   t.PA = take(lfsr_branch_bwd_partial_floats(B, c->A, h, w));
-  for (int i = 0; i < 2; ++i) t.PW[i] = take((size_t)256 * 9 * 64 * 64);   // the 3x3 weight gradients' slabs, alternating: the reduce of one runs beside the next op
   t.small = take(64 * 1024);
   t.total = o;
 }
@@ -459,7 +456,7 @@ int lfsr_distgssr_forward_train(lfsr_distgssr* c, const float* x, float* out, in
   TrainWs t;
   train_layout(c, B, h, w, (float*)workspace, t);
   if (workspace_bytes < t.total * sizeof(float)) return LFSR_E_WS;
-  if ((long long)B * c->A * c->A * h * w >= (1LL << 31) / 144) return LFSR_E_ARG;
+  if ((long long)B * c->A * c->A * h * w * 160 * 4 >= (1LL << 30)) return LFSR_E_ARG;   // (as in the forward)
   const int A = c->A, AA = A * A, nimg = B * AA;
   const float L = 0.1f;
   hipStream_t st = lfsr_stream(stream);
@@ -497,8 +494,20 @@ int lfsr_distgssr_forward_train(lfsr_distgssr* c, const float* x, float* out, in
   return LFSR_OK;
 }
 
+static int distgssr_backward_impl(lfsr_distgssr* c, const float* x, const float* dout, int B, int h, int w, void* workspace, size_t workspace_bytes,
+                                  float* grads, size_t n_grads, void* stream);
+
 int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, int B, int h, int w, void* workspace, size_t workspace_bytes,
                            float* grads, size_t n_grads, void* stream) {
+  const int rc = distgssr_backward_impl(c, x, dout, B, h, w, workspace, workspace_bytes, grads, n_grads, stream);
+  // An error return between a fork and its join would leave side-stream kernels queued that still read and write the caller's workspace and gradient bucket:
+  // whatever the failure was, both streams are drained before the caller gets the buffers back.
+  if (rc != LFSR_OK && c && c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamSynchronize(lfsr_stream(stream)); }
+  return rc;
+}
+
+static int distgssr_backward_impl(lfsr_distgssr* c, const float* x, const float* dout, int B, int h, int w, void* workspace, size_t workspace_bytes,
+                                  float* grads, size_t n_grads, void* stream) {
   if (!c || !x || !dout || !workspace || !grads || B <= 0 || h <= 0 || w <= 0 || !c->finalized || n_grads != c->n_params) return LFSR_E_ARG;
   if (!(c->A & 1)) return LFSR_E_ARG;   // the EPI data gradient's line-shift gathers assume the symmetric padding of odd angRes
   TrainWs t;
@@ -511,16 +520,11 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   int rc;
 #define RC(call) do { rc = (call); if (rc) return rc; } while (0)
   auto G = [&](const std::string& k) -> float* { return grads + c->slots.at(k).grad_off; };
-  // The weight gradient and the data gradient of a 3x3 layer read the same dY and are independent: the weight gradient goes to a side stream (fork: an event
-  // recorded on the caller's stream once dY exists) and the caller's stream joins it right behind the data gradient, before anything may overwrite dY, the
-  // saved activation or the partial slabs.  At B = 8 the persistent conv kernel leaves 224 of 256 CUs idle in its fourth tile round (800 tiles): the weight
-  // gradient's blocks could fill them.  MEASURED NEGATIVE (round 3, two runs each in one call, profiles/r03_logs/c6_overlap.txt): 25.3 ms with the side stream against
-  // 24.5 ms on one stream -- both kernels are persistent one-block-per-CU grids (159 KB / 115 KB of LDS: never co-resident on a CU), so interleaving their blocks only
-  // lengthens both.  Kept as an option: LFSR_BWD_OVERLAP=1.  Every wgrad3 is followed by its dgrad3 below.  Not under stream capture.
-  bool overlap = false, overlap_br = false, overlap_pw = false, overlap_red = false;
+  // Two streams for the branch gradients only (below; LFSR_BWD_OVERLAP=0 under LFSR_LAB keeps one stream).  Measured negative or neutral in round 3 and removed in
+  // round 4 (profiles/r03_logs/c6_overlap.txt, train_overlap_ab.txt): the 3x3 weight gradients beside their data gradients (25.3 vs 24.5 ms: both are persistent
+  // one-block-per-CU grids), fuse.0's weight gradient beside its data gradient, the slab reduces on the side stream.  Not under stream capture.
+  bool overlap_br = false;
   {
-    // LFSR_BWD_OVERLAP: bit 0 = the 3x3 weight gradients beside their data gradients (measured negative, off); bit 1 = the small launches of the angular branch's
-    // backward beside those of the epipolar branch, and EPIConv.0's weight gradient beside the read-modify-write chain of dx (default on: unset = "2")
     const char* osel = lfsr_sel("LFSR_BWD_OVERLAP");
     const int omode = osel ? atoi(osel) : 2;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -529,52 +533,20 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         bool ok = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c->ev_w, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->ev_red[0], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_red[1], hipEventDisableTiming) == hipSuccess;
         if (!ok) { if (c->side) (void)hipStreamDestroy(c->side); c->side = nullptr; }
       }
-      overlap = c->side != nullptr && (omode & 1);
       overlap_br = c->side != nullptr && (omode & 2);
-      overlap_pw = c->side != nullptr && (omode & 4);      // fuse.0's weight gradient beside its data gradient (A/B)
-      overlap_red = c->side != nullptr && (omode & 8) && !overlap;   // the slab reduce of a 3x3 weight gradient on the side stream, beside the data gradient that follows
     }
   }
-  bool forked = false;
-  int nred = 0;
   // weight gradient of a 3x3 conv: dW[tap][n][k] = sum_m g[m][n] * xin[conv3 src(m,tap)][k]
   auto wgrad3 = [&](const std::string& key, const float* xin, const float* g, int g_stride) -> int {
-    hipStream_t ws = st;
-    if (overlap) {
-      if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return LFSR_E_ARG;
-      ws = c->side; forked = true;
-    }
-    if (overlap_red) {
-      // the weight gradient itself stays on the caller's stream; its 11-us slab reduce (37.7 MB of partials, no LDS, small blocks) goes to the side stream, where it
-      // runs beside the persistent data-gradient kernel that follows.  Two slab buffers alternate: before a buffer is written again the caller's stream waits for the
-      // reduce that read it two weight gradients ago.
-      const int b = nred & 1;
-      if (nred >= 2 && hipStreamWaitEvent(st, c->ev_red[b], 0) != hipSuccess) return LFSR_E_ARG;
-      int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.PW[b], nimg, h, w, st);
-      if (r) return r;
-      if (hipEventRecord(c->ev_w, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_w, 0) != hipSuccess) return LFSR_E_ARG;
-      r = lfsr_wgrad_reduce(t.PW[b], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, c->side);
-      if (hipEventRecord(c->ev_red[b], c->side) != hipSuccess) return LFSR_E_ARG;
-      ++nred;
-      return r;
-    }
-    int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.P[0], nimg, h, w, ws);
-    if (!r) r = lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, ws);
-    if (overlap && hipEventRecord(c->ev_join, c->side) != hipSuccess) return LFSR_E_ARG;
+    int r = lfsr_wgrad_conv3_launch(g, g_stride, 0, xin, 64, 0, t.P[0], nimg, h, w, st);
+    if (!r) r = lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_conv3_blocks(nimg, h, w), nullptr, 0, G(key), 64, 64, 9, 0, 0, 0, 0, 0, st);
     return r;
   };
   auto dgrad3 = [&](const float* dy, int dy_stride, const std::string& key, float* dx, const float* r1, const float* r2_unused, const float* mk, int mk_stride) -> int {
     (void)r2_unused;
-    const int r = lfsr_conv3x3_bwd_data(dy, dy_stride, 0, c->wT(key), dx, 64, 0, r1, 64, 0, mk, mk_stride, 0, L, nimg, h, w, st);
-    if (forked) {                        // join: the caller's stream continues only after the side stream's weight gradient
-      forked = false;
-      if (hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) return LFSR_E_ARG;
-    }
-    return r;
+    return lfsr_conv3x3_bwd_data(dy, dy_stride, 0, c->wT(key), dx, 64, 0, r1, 64, 0, mk, mk_stride, 0, L, nimg, h, w, st);
   };
   auto pick = [&](const float* a, const float* b, const float* d) -> float* {
     for (int i = 0; i < 4; ++i)
@@ -618,22 +590,16 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
       RC(wgrad3(p + "fuse.2.weight", t.FZ[i], gy, 64));
       RC(dgrad3(gy, 64, p + "fuse.2.weight", t.dF, nullptr, nullptr, t.FZ[i], 64));
       // fuse.0 : FZ = lrelu(1x1(CAT))
-      {   // streaming kernel (every row of dF and CAT read once, one slab per block); else the generic split-K kernel.  (overlap_pw: on the side stream beside the data gradient)
-        hipStream_t ws = st;
-        if (overlap_pw) {
-          if (hipEventRecord(c->ev_fork, st) != hipSuccess || hipStreamWaitEvent(c->side, c->ev_fork, 0) != hipSuccess) return LFSR_E_ARG;
-          ws = c->side;
-        }
-        float* Pw = t.PA;                 // (its own slab buffer: P[0] belongs to the main stream's weight gradients)
-        int rc5 = lfsr_wgrad_pw144_launch(t.dF, 64, 0, t.CAT[i], 144, 0, Pw, npix, ws);
+      {   // streaming kernel (every row of dF and CAT read once, one slab per block); else the generic split-K kernel
+        float* Pw = t.PA;
+        int rc5 = lfsr_wgrad_pw144_launch(t.dF, 64, 0, t.CAT[i], 144, 0, Pw, npix, st);
         int slabs = lfsr_wgrad_pw144_blocks(npix);
         if (rc5 == LFSR_E_ARG) {
-          ws = st; Pw = t.P[0];           // generic split-K kernel: larger slabs, one stream
-          rc5 = lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.dF, 64, 0, t.CAT[i], 144, 0, Pw, npix, 64, 144, 1, h, w, 1, ws); slabs = lfsr_wgrad_splits(npix, 1, 144);
+          Pw = t.P[0];                    // generic split-K kernel: larger slabs
+          rc5 = lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, t.dF, 64, 0, t.CAT[i], 144, 0, Pw, npix, 64, 144, 1, h, w, 1, st); slabs = lfsr_wgrad_splits(npix, 1, 144);
         }
         RC(rc5);
-        RC(lfsr_wgrad_reduce(Pw, slabs, nullptr, 0, G(p + "fuse.0.weight"), 64, 144, 1, 0, 0, 0, 0, 0, ws));
-        if (overlap_pw && hipEventRecord(c->ev_join, c->side) != hipSuccess) return LFSR_E_ARG;
+        RC(lfsr_wgrad_reduce(Pw, slabs, nullptr, 0, G(p + "fuse.0.weight"), 64, 144, 1, 0, 0, 0, 0, 0, st));
       }
       {
         LfsrGemm q{};
@@ -641,7 +607,6 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
         q.Y = t.dCAT; q.y_stride = 144; q.Mk = t.CAT[i]; q.mk_stride = 144; q.mk_slope = L;
         q.M = npix; q.N = 144; q.A = 1; q.h = 1; q.w = 1; q.ntaps = 1; q.CH = 144;
         RC(lfsr_bwd_gemm(q, st));
-        if (overlap_pw && hipStreamWaitEvent(st, c->ev_join, 0) != hipSuccess) return LFSR_E_ARG;
       }
       // SpaConv : CAT[0:64] = lrelu(conv(S1)), S1 = lrelu(conv(Xin))
       RC(wgrad3(p + "SpaConv.2.weight", t.S1[i], t.dCAT, 144));
@@ -684,9 +649,6 @@ int lfsr_distgssr_backward(lfsr_distgssr* c, const float* x, const float* dout, 
   RC(lfsr_init_gather9(x, t.XG9, B, A, h, w, st));
   RC(lfsr_wgrad_launch(LFSR_IN_SAME, LFSR_IN_SAME, gcur, 64, 0, t.XG9, 16, 0, t.P[0], npix, 64, 16, 1, h, w, 1, st));
   RC(lfsr_wgrad_reduce(t.P[0], lfsr_wgrad_splits(npix, 1, 16), nullptr, 0, G("init_conv.weight"), 64, 16, 1, 0, 0, 0, 9, 0, st));
-  if (overlap_red)      // the caller's stream owns the gradient bucket again only after the last side-stream reduces
-    for (int b = 0; b < 2 && b < nred; ++b)
-      if (hipStreamWaitEvent(st, c->ev_red[b], 0) != hipSuccess) return LFSR_E_ARG;
 #undef RC
   return LFSR_OK;
 }

@@ -59,7 +59,7 @@ __device__ __forceinline__ void eb_split8(const f32x4e lo, const f32x4e hi, u32x
   for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
 
-// asm MFMA with the accumulator tied (conv3x3_wino4b.hip: the builtin's register allocation may overlap vDst with a source partially)
+// asm MFMA with the accumulator tied (rowgemm_b3.hip, b3_mfma: why not the builtin)
 __device__ __forceinline__ void eb_mfma(f32x4e& c, const u32x4e a, const u32x4e b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }

@@ -88,7 +88,7 @@ int lfsr_epit_forward(lfsr_epit* c, const float* x, float* out, int B, int h, in
   if (workspace_bytes < tot * sizeof(float)) return LFSR_E_WS;
   const int A = c->A, AA = A * A, nimg = B * AA, HW = h * w;
   const long long npix = (long long)nimg * HW;
-  if (npix >= (1LL << 31) / 256) return LFSR_E_ARG;
+  if (npix * 256 * 4 >= (1LL << 31)) return LFSR_E_ARG;   // every activation tensor < 2 GiB (the q | k rows are the widest): the kernels' 32-bit byte offsets; callers split the batch (capi.py)
   float* ws = (float*)workspace;
   float *F0 = ws + off[0], *BUF0 = ws + off[1], *Pb = ws + off[2], *Qb = ws + off[3], *MID = ws + off[4], *Y = ws + off[5], *C1 = ws + off[6], *C2 = ws + off[7];
   float *T = ws + off[8], *TN = ws + off[9], *V = ws + off[10], *T2 = ws + off[11], *QK = ws + off[12], *HR = ws + off[13];

@@ -39,7 +39,7 @@ __device__ __forceinline__ void c3_split8(const float a[8], u32x4c& p0, u32x4c& 
 #pragma unroll
   for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
-// asm MFMA, accumulator tied (conv3x3_wino4b.hip explains why not the builtin)
+// asm MFMA, accumulator tied (rowgemm_b3.hip, b3_mfma: why not the builtin)
 __device__ __forceinline__ void c3_mfma(f32x16c& c, const u32x4c a, const u32x4c b) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }

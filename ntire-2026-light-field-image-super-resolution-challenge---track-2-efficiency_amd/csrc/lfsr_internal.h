@@ -55,7 +55,7 @@ struct LfsrOpTimer {
   LfsrOpTimer(const LfsrOpTimer&) = delete;
   LfsrOpTimer& operator=(const LfsrOpTimer&) = delete;
  private:
-  int slot_;
+  int slot_, gen_;
   hipStream_t st_;
 };
 
@@ -74,26 +74,12 @@ int lfsr_conv3x3_halo_tail_launch(const float* x, int x_stride, int x_choff, con
 // The Winograd part is the F(2x2,3x3) pack (LFSR_CONV3_WINO2_FLOATS) followed by the F(4x4,3x3) pack of conv3x3_wino4.hip.
 #define LFSR_CONV3_WINO2_FLOATS (16 * 64 * 64)
 #define LFSR_CONV3_WINO4_FLOATS (36 * 64 * 64)
-// ... followed by the same F(4x4,3x3) U in the per-wave record order of the symmetric-wave kernel, conv3x3_wino4s.hip
-#define LFSR_CONV3_WINO4S_FLOATS (36 * 64 * 64)
-// ... followed by the F(4x4,3x3) U split into three bf16 terms per weight (6 B instead of 4), conv3x3_wino4b.hip
-#define LFSR_CONV3_WINO4B_FLOATS (54 * 64 * 64)
-#define LFSR_CONV3_WINO_FLOATS (LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS + LFSR_CONV3_WINO4S_FLOATS + LFSR_CONV3_WINO4B_FLOATS)
-int lfsr_pack_wino4b(const float* direct_packed, float* out, hipStream_t st);
-int lfsr_conv3x3_wino4b_launch(const float* x, int x_stride, int x_choff, const float* w_wino4b, float* y, int y_stride, int y_choff,
-                               const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
-                               const float* mk, int mk_stride, int mk_choff, float mk_slope,
-                               int n_img, int h, int w, float slope, hipStream_t st);
-int lfsr_pack_wino4s(const float* direct_packed, float* out, hipStream_t st);
-int lfsr_conv3x3_wino4s_launch(const float* x, int x_stride, int x_choff, const float* w_wino4s, float* y, int y_stride, int y_choff,
-                               const float* r1, int r1_stride, int r1_choff, const float* r2, int r2_stride, int r2_choff,
-                               const float* mk, int mk_stride, int mk_choff, float mk_slope,
-                               int n_img, int h, int w, float slope, hipStream_t st);
+#define LFSR_CONV3_WINO_FLOATS (LFSR_CONV3_WINO2_FLOATS + LFSR_CONV3_WINO4_FLOATS)
 int lfsr_pack_wino(const float* direct_packed, float* out, hipStream_t st);   // every Winograd-domain copy (the operator-level pack)
-// ... or only the copies in `mask` (LFSR_W_WINO2 | LFSR_W_WINO4 | LFSR_W_WINO4S | LFSR_W_WINO4B).  The model runtimes repack every weight each
+// ... or only the copies in `mask` (LFSR_W_WINO2 | LFSR_W_WINO4).  The model runtimes repack every weight each
 // training step and write only what the selected 3x3 kernel reads: lfsr_conv3_variant_mask() = the copies LFSR_CONV3X3 selects (default: wino4).
 // The selection is read when weights are packed AND when a conv is launched: set it before loading a model.
-enum { LFSR_W_WINO2 = 1, LFSR_W_WINO4 = 2, LFSR_W_WINO4S = 4, LFSR_W_WINO4B = 8, LFSR_W_ALL = 15 };
+enum { LFSR_W_WINO2 = 1, LFSR_W_WINO4 = 2, LFSR_W_ALL = 3 };
 int lfsr_conv3_variant_mask();          // union of the copies the forward (LFSR_CONV3X3) and the data-gradient (LFSR_DGRAD3) selections read
 const char* lfsr_conv3_fwd_sel();
 const char* lfsr_conv3_dgrad_sel();

@@ -42,7 +42,7 @@ struct LnLinArgs {
   int nstages;
 };
 
-__device__ __forceinline__ void ll_mfma(f32x4l& c, const u32x4l a, const u32x4l b) {      // accumulator tied (conv3x3_wino4b.hip: why not the builtin)
+__device__ __forceinline__ void ll_mfma(f32x4l& c, const u32x4l a, const u32x4l b) {      // accumulator tied (rowgemm_b3.hip, b3_mfma: why not the builtin)
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void ll_split8(const float (&a)[8], u32x4l& p0, u32x4l& p1, u32x4l& p2) {

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -19,6 +20,7 @@ namespace {
 struct Rec { const char* op; int a, b; hipEvent_t e0, e1; };
 std::mutex g_mu;
 std::vector<Rec> g_recs;
+int g_gen = 0;      // bumped whenever g_recs is emptied: a timer that began in an older generation finds its record gone and records nothing
 std::vector<hipEvent_t> g_free;
 
 hipEvent_t get_event() {
@@ -29,20 +31,24 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-LfsrOpTimer::LfsrOpTimer(const char* op, int a, int b, hipStream_t st) : slot_(-1), st_(st) {
+LfsrOpTimer::LfsrOpTimer(const char* op, int a, int b, hipStream_t st) : slot_(-1), gen_(0), st_(st) {
   if (!g_lfsr_op_profile_on.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lk(g_mu);
   Rec r{op, a, b, get_event(), get_event()};
   if (!r.e0 || !r.e1) return;
   (void)hipEventRecord(r.e0, st);
   slot_ = (int)g_recs.size();
+  gen_ = g_gen;
   g_recs.push_back(r);
 }
 
+// A read or a switch on another thread between the two ends of a timer empties the table (and recycles the events): the generation says so and the
+// timer then records nothing rather than stamping another operator's record.  Hooked times of operators that run on two streams at once (the
+// branch backward of the training step) overlap in wall time: their sum exceeds the step's (bench.py reports shares of hooked time, not of the step).
 LfsrOpTimer::~LfsrOpTimer() {
   if (slot_ < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);
-  if (slot_ < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot_].e1, st_);
+  if (gen_ == g_gen && slot_ < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot_].e1, st_);
 }
 
 extern "C" {
@@ -51,6 +57,7 @@ int lfsr_op_profile(int enable) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& r : g_recs) { g_free.push_back(r.e0); g_free.push_back(r.e1); }
   g_recs.clear();
+  ++g_gen;
   g_lfsr_op_profile_on.store(enable ? 1 : 0);
   return LFSR_OK;
 }
@@ -70,6 +77,7 @@ long long lfsr_op_profile_read(char* buf, size_t cap) {
     g_free.push_back(r.e0); g_free.push_back(r.e1);
   }
   g_recs.clear();
+  ++g_gen;
   std::string out;
   char line[256];
   for (auto& kv : agg) {

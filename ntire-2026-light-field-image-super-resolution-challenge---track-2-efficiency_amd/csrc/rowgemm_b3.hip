@@ -50,7 +50,10 @@ __device__ __forceinline__ void b3_split8(const float4 lo, const float4 hi, u32x
   for (int j = 0; j < 4; ++j) { unsigned t0, t1, t2; lfsr_split_pair(a[2 * j], a[2 * j + 1], t0, t1, t2); p0[j] = t0; p1[j] = t1; p2[j] = t2; }
 }
 
-// asm MFMA with the accumulator tied (see conv3x3_wino4b.hip: the builtin's register allocation may overlap vDst with a source partially)
+// asm MFMA with the accumulator tied ("+v": vDst = SrcC, disjoint from the A / B registers).  With the builtins the register allocator may give a bf16 MFMA a vDst that
+// overlaps its SrcB / SrcC PARTIALLY (it models 4-register results as read-before-write); on gfx950 that returns garbage in the overlapping registers (found in round 2 with
+// debug builds of a split-bf16 form of the 3x3 conv, since retired: every product group whose result landed on such an allocation was wrong).  Every b3 kernel issues its
+// MFMAs this way.
 __device__ __forceinline__ void b3_mfma(f32x4b& c, const u32x4b a, const u32x4b b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }

@@ -42,7 +42,7 @@ def test_host_only_entry_points():
         assert lib.lfsr_lf_divide(None, None, 5, h0, w0, 32, 16, 4, C.byref(nu), C.byref(nv), None) == 0
         assert (nu.value, nv.value) == (eu, ev)      # SURVEY 8c expected counts
     assert lib.lfsr_lf_divide(None, None, 5, 0, 8, 32, 16, 4, None, None, None) == -1
-    assert lib.lfsr_packed_weight_floats(64, 64, 9) == (9 + 16 + 36 + 36 + 54) * 64 * 64   # direct pack + the F(2x2,3x3), the two fp32 F(4x4,3x3) and the split-bf16 F(4x4,3x3) Winograd-domain copies
+    assert lib.lfsr_packed_weight_floats(64, 64, 9) == (9 + 16 + 36) * 64 * 64   # direct pack + the F(2x2,3x3) and F(4x4,3x3) Winograd-domain copies
     assert lib.lfsr_packed_weight_floats(64, 128, 9) == 9 * 64 * 128
     assert lib.lfsr_packed_weight_floats(400, 16, 1) == 416 * 16
     ctx = C.c_void_p()

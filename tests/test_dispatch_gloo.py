@@ -116,3 +116,51 @@ def test_two_rank_scene_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert ret.get(0) is True and ret.get(1) is True
+
+
+def test_device_buffer_exchange_branch_with_a_fake_rccl_backend(monkeypatch):
+    """The exchange an N-GPU run takes (backend 'nccl': the padded tile buffer goes to dist.gather / dist.all_gather AS IT IS, no host staging -- dispatch.py,
+    `host_xchg`) driven rank by rank in one process: a fake process group records what each rank hands to the collective and plays the other ranks' buffers back."""
+    import lfsr_amd.dispatch  # noqa: F401  (the module under test resolves torch.distributed at call time)
+    A, world = 5, 3
+    lr = torch.arange(A * 40 * A * 33, dtype=torch.float32).reshape(A * 40, A * 33)      # 9 patches over 3 ranks
+    sent, state = {}, {"rank": 0, "calls": []}
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: world)
+    monkeypatch.setattr(dist, "get_rank", lambda group=None: state["rank"])
+    monkeypatch.setattr(dist, "get_backend", lambda group=None: "nccl")
+
+    def fake_gather(t, gather_list=None, dst=0, group=None):
+        state["calls"].append(("gather", state["rank"], dst, t.device.type, tuple(t.shape)))
+        sent[state["rank"]] = t.clone()
+        if state["rank"] == dst:
+            assert gather_list is not None and len(gather_list) == world
+            for r in range(world):
+                gather_list[r].copy_(sent[r])
+        else:
+            assert gather_list is None
+
+    def fake_all_gather(out_list, t, group=None):
+        state["calls"].append(("all_gather", state["rank"], None, t.device.type, tuple(t.shape)))
+        sent[state["rank"]] = t.clone()
+        if len(sent) == world:
+            for r in range(world):
+                out_list[r].copy_(sent[r])
+
+    monkeypatch.setattr(dist, "gather", fake_gather)
+    monkeypatch.setattr(dist, "all_gather", fake_all_gather)
+    # gather to rank 0: the other ranks run first (their buffers are what rank 0's gather receives)
+    for r in (2, 1, 0):
+        state["rank"] = r
+        out = sr_scene(fake_net, lr, A, 4, ops=OracleOps, minibatch=2, dst=0)
+        assert (out is None) == (r != 0)
+    assert torch.equal(out, expected(lr, A))
+    shapes = {c[4] for c in state["calls"]}
+    assert shapes == {(3, A, A, 64, 64)}, shapes                 # every rank hands over the same padded (cap, A, A, stride*s, stride*s) buffer: one equal-size collective
+    assert all(c[0] == "gather" and c[2] == 0 for c in state["calls"]) and len(state["calls"]) == world
+    # all-gather form: the last rank to call sees every buffer and assembles the scene
+    sent.clear(); state["calls"].clear()
+    for r in (0, 1, 2):
+        state["rank"] = r
+        out = sr_scene(fake_net, lr, A, 4, ops=OracleOps, minibatch=4, dst=None)
+    assert torch.equal(out, expected(lr, A))

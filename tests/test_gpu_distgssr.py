@@ -67,7 +67,7 @@ def test_conv3x3_wide_views(B, A, h, w, monkeypatch):
     ref = O.leaky_relu(O.conv2d(x.astype(np.float64), wt.astype(np.float64), dilation=(A, A), padding=(A, A)), 0.1) + r1
     wp = capi.pack_conv_weight(dev(wt))
     xv, rv = to_vcl(x, A), to_vcl(r1, A)
-    for sel in ("", "wino2", "halo", "wino4s", "wino4b"):
+    for sel in ("", "wino2", "halo"):
         if sel: monkeypatch.setenv("LFSR_CONV3X3", sel)
         else: monkeypatch.delenv("LFSR_CONV3X3", raising=False)
         y = capi.conv3x3(xv, wp, B * A * A, h, w, slope=0.1, res1=rv)
@@ -80,7 +80,7 @@ def test_packed_conv_weight_carries_winograd_copy():
     """lfsr_pack_conv_weight(64,64,3,3) = direct [9][64][64] pack followed by U = G g Gt in the fragment order of the kernel"""
     wt = rnd((64, 64, 3, 3), 21, 0.05)
     wp = capi.pack_conv_weight(dev(wt)).cpu().numpy()
-    assert wp.size == (9 + 16 + 36 + 36 + 54) * 64 * 64
+    assert wp.size == (9 + 16 + 36) * 64 * 64
     direct = wt.reshape(64, 64, 9).transpose(2, 0, 1).reshape(-1)           # [tap][n][k]
     assert np.array_equal(wp[:9 * 64 * 64], direct)
     ref = O.winograd_pack(wt)
@@ -89,17 +89,6 @@ def test_packed_conv_weight_carries_winograd_copy():
     ref4 = O.winograd4_pack(wt)                                             # F(4x4,3x3) copy (conv3x3_wino4.hip)
     w4 = wp[25 * 64 * 64:61 * 64 * 64]
     assert np.abs(w4 - ref4).max() <= 1e-8 and np.mean(w4 == ref4) > 0.99
-    # the same U once more in the per-wave record order of the symmetric-wave kernel (conv3x3_wino4s.hip): a permutation of the values above
-    w4s = wp[61 * 64 * 64:97 * 64 * 64]
-    assert w4s.size == 36 * 64 * 64 and np.abs(np.sort(w4s) - np.sort(w4)).max() <= 1e-8    # (fp64 contraction may differ in the last bit)
-    # ... and as three bf16 terms per weight (conv3x3_wino4b.hip): U1 [144][4][64][(u0, u1)][4] then U2 [144][4][64][4]; u0 + u1 + u2 == U exactly
-    reg = wp[97 * 64 * 64:].view(np.uint16)
-    U1 = reg[:144 * 4 * 64 * 8].reshape(144, 4, 64, 2, 4); U2 = reg[144 * 4 * 64 * 8:].reshape(144, 4, 64, 4)
-    bf = lambda a: (a.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
-    tot = bf(U1[:, :, :, 0]) + bf(U1[:, :, :, 1]) + bf(U2)                                   # [step = chunk * 36 + p][ns][lane = 16 (k / 4 % 4) + n % 16][k % 4]
-    back = tot.reshape(4, 36, 4, 4, 16, 4).transpose(1, 2, 4, 0, 3, 5).reshape(36, 64, 64)   # [p][n][k]
-    ref_pnk = O.winograd4_weights(wt.astype(np.float64)).reshape(36, 64, 64).astype(np.float32).astype(np.float64)   # [p = 6 xi + nu][n][k]
-    assert np.abs(back - ref_pnk).max() <= 1e-8 and np.mean(back == ref_pnk) > 0.99   # the three terms add up to the fp32 U exactly
 
 
 def test_conv3x3_tail_and_fallback_kernels(monkeypatch):
@@ -145,12 +134,6 @@ def test_conv3x3_bench_size_properties(monkeypatch):
     monkeypatch.delenv("LFSR_CONV3X3")
     torch.cuda.synchronize()
     assert float((y2 - yd).abs().max()) < 2e-5                      # F(2x2,3x3): two fp32 evaluation orders of the same sums
-    monkeypatch.setenv("LFSR_CONV3X3", "wino4b")
-    yb = capi.conv3x3(x, wp, n_img, h, w, slope=0.1, res1=r)
-    monkeypatch.delenv("LFSR_CONV3X3")
-    torch.cuda.synchronize()
-    assert float((yb - yd).abs().max()) < 2e-4                      # the same F(4x4,3x3) with three-term bf16 operands on the bf16 MFMA pipe
-    assert float((yb - yw).abs().max()) < 2e-4
     # linearity (slope 1, no residual): conv(2 x - 3 z) == 2 conv(x) - 3 conv(z)
     lin = capi.conv3x3(2.0 * x - 3.0 * z, wp, n_img, h, w, slope=1.0)
     ref = 2.0 * capi.conv3x3(x, wp, n_img, h, w, slope=1.0) - 3.0 * capi.conv3x3(z, wp, n_img, h, w, slope=1.0)

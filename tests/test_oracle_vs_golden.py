@@ -239,7 +239,7 @@ def test_winograd4_roundoff_through_the_whole_network():
 
 
 def test_split_bf16_products():
-    """the arithmetic of conv3x3_wino4b.hip restated in numpy: fp32 operands as three bf16 terms (input: truncation, exact; weights: round to
+    """the arithmetic of the b3 kernels (rowgemm_b3.hip, epi_b3.hip, ffn_b3.hip, ...) restated in numpy: fp32 operands as three bf16 terms (input: truncation, exact; weights: round to
     nearest), six of the nine cross products -> closer to the fp64 dot product than an fp32 dot product is, and the split itself is exact"""
     rng = np.random.default_rng(0)
     def trunc(x): return (x.astype(np.float32).view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
