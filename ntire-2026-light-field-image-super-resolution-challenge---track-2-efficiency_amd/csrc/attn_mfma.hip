@@ -12,9 +12,12 @@
 //   O^T tile += V_tile^T P_tile^T      A = V^T [d = lane & 15][key = 4 g + r], B = P^T = the S^T accumulator registers AS THEY STAND
 //                                     (D layout: lane (q, g), register r = key 4 g + r -- exactly the B operand of step r)
 //   out[q][head 16 + 4 g .. + 3] = O^T / l : 16 B per lane.
-// K (rows rotated by chunk so the A-operand ds_read_b128 of 16 keys is conflict-free) and V^T (rows rotated by 4 d) of a head are staged
-// in LDS once per sequence: 20 KB per head, a 512-thread block = 4 heads x 2 waves (each wave takes every other query tile), 80 KB
-// -> two blocks per CU.
+// K [token][16] and V^T [key tile][d][16 keys] of a head are staged in LDS once per sequence: 20 KB per head, a 512-thread block = 4 heads x 2 waves (each
+// wave takes every other query tile), 80 KB -> two blocks per CU.  The 16-B chunks of a row sit at swizzled positions so that the A-operand ds_read_b128
+// are conflict-free for the lane groups the hardware actually serves together ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 --
+// MI355X_MICROARCH.md, LDS): K chunk c of token t at (c + ((t >> 2) & 2)) & 3, V^T chunk j of row d at j ^ ((-(d >> 2)) & 3).  The round-2 rotations (by
+// t >> 2 and by 4 d) were conflict-free for CONTIGUOUS groups of 16 lanes and two-way conflicted on the real ones (SQ_LDS_BANK_CONFLICT 39 % of the
+// LDS-active cycles, profiles/r03_logs/pmc_epit_sq_summary.json).
 #include <math.h>
 
 #include "lfsr_internal.h"
@@ -36,22 +39,25 @@ struct EpiAttnArgs {
   int L;           // n1 * n2
 };
 
+#ifndef EA_HB
+#define EA_HB 4     // heads per block (two waves each): 4 -> 512 threads and 80 KB of LDS, 2 -> 256 threads and 40 KB
+#endif
 template <int NT, int N1>      // N1: the angular resolution when known at compile time (5: the BASELINE geometry; divisions by it become multiplies), 0: read from the arguments
-__global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
+__global__ __launch_bounds__(EA_HB * 128) void k_epi_attn_mfma(EpiAttnArgs p) {
   const int n1 = N1 ? N1 : p.n1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LR = NT * 16;                 // padded sequence length
   constexpr int HEAD_FLOATS = LR * 16 * 2;    // K [LR][16] + V^T [16][LR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h4 = wave >> 1, half = wave & 1, l15 = lane & 15, g = lane >> 4;
-  const int hblocks = p.nheads >> 2;
+  const int hblocks = p.nheads / EA_HB;
   const int hq = blockIdx.x % hblocks;
   int t = blockIdx.x / hblocks;
   const int s2 = t % p.ns2; t /= p.ns2;
   const int s1 = t % p.ns1;
   const int s0 = t / p.ns1;
   const long long base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
-  const int head = hq * 4 + h4;
+  const int head = hq * EA_HB + h4;
   float* const sK = smem + h4 * HEAD_FLOATS;
   float* const sVt = sK + LR * 16;
 
@@ -78,14 +84,10 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
       const int idx = t128 + 128 * it;
       if (idx < LR * 4) {
         const int tok = idx >> 2, c = idx & 3;
-        *reinterpret_cast<f32x4a*>(sK + tok * 16 + (((c + (tok >> 2)) & 3) << 2)) = kv[it];
+        *reinterpret_cast<f32x4a*>(sK + tok * 16 + (((c + ((tok >> 2) & 2)) & 3) << 2)) = kv[it];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int d = 4 * c + jj;
-          int col = tok + 4 * d;
-          col = col >= LR ? col - LR : col;
-          sVt[d * LR + col] = vv[it][jj];
-        }
+        for (int jj = 0; jj < 4; ++jj)      // V^T [key tile][d = 4 c + jj][16 keys], the 16-B chunk of four keys at position chunk ^ ((-c) & 3)
+          sVt[(tok >> 4) * 256 + (4 * c + jj) * 16 + (((((tok >> 2) & 3) ^ ((4 - c) & 3))) << 2) + (tok & 3)] = vv[it][jj];
       }
     }
   }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
       // (S[kt] of a key tile outside [ktlo, kthi] is never read: the second loop skips the same tiles -- initialising it cost a register copy per element on the skipped path)
       if (kt >= ktlo && kt <= kthi) {
         const int krow = kt * 16 + l15;
-        const f32x4a ka = *reinterpret_cast<const f32x4a*>(sK + krow * 16 + (((g + (krow >> 2)) & 3) << 2));
+        const f32x4a ka = *reinterpret_cast<const f32x4a*>(sK + krow * 16 + (((g + ((krow >> 2) & 2)) & 3) << 2));
         f32x4a acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qb.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qb.y, acc, 0, 0, 0);
@@ -153,9 +155,7 @@ __global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
           pw[r] = __builtin_amdgcn_exp2f(S[kt][r] - m);     // raw v_exp_f32 (the argument is <= 0: no range handling needed; results below 2^-126 flush to 0).  exp2(-inf) = 0 on masked keys; an empty band gives NaN exactly like softmax over an all -inf row
           den += pw[r];
         }
-        int col = kt * 16 + 4 * g + 4 * l15;
-        col = col >= LR ? col - LR : col;
-        const f32x4a va = *reinterpret_cast<const f32x4a*>(sVt + l15 * LR + col);
+        const f32x4a va = *reinterpret_cast<const f32x4a*>(sVt + kt * 256 + l15 * 16 + ((g ^ ((4 - (l15 >> 2)) & 3)) << 2));
         o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, pw.x, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, pw.y, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, pw.z, o, 0, 0, 0);
@@ -176,7 +176,7 @@ int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
                               float* o, int o_stride, int o_choff, int nheads, int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
                               int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, hipStream_t st) {
   const int L = n1 * n2;
-  if (nheads % 4 || L > 160 || L < 1 || l1 < n1 - 1 || r1 < n1) return LFSR_E_ARG;    // every angular position visible; <= 10 tiles of 16 tokens
+  if (nheads % EA_HB || L > 160 || L < 1 || l1 < n1 - 1 || r1 < n1) return LFSR_E_ARG;    // every angular position visible; <= 10 tiles of 16 tokens
   EpiAttnArgs p{};
   p.Q = q; p.q_stride = q_stride; p.q_choff = q_choff; p.K = k; p.k_stride = k_stride; p.k_choff = k_choff;
   p.V = v; p.v_stride = v_stride; p.v_choff = v_choff; p.O = o; p.o_stride = o_stride; p.o_choff = o_choff;
@@ -184,10 +184,10 @@ int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
   p.n1 = n1; p.n2 = n2; p.st1 = st1; p.st2 = st2; p.l2 = l2; p.r2 = r2; p.clip2 = clip2 > 0 ? clip2 : n2;
   p.scale = (1.0f / sqrtf(16.0f)) * 1.44269504088896340736f;
   p.L = L;
-  const long long nblk = (long long)ns0 * ns1 * ns2 * (nheads / 4);
+  const long long nblk = (long long)ns0 * ns1 * ns2 * (nheads / EA_HB);
   if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;
   constexpr int NT = 10;
-  const int smem = 4 * NT * 16 * 16 * 2 * 4;   // 81920
+  const int smem = EA_HB * NT * 16 * 16 * 2 * 4;   // 81920 at four heads per block
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
@@ -197,8 +197,8 @@ int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
-  if (n1 == 5) hipLaunchKernelGGL((k_epi_attn_mfma<NT, 5>), dim3((unsigned)nblk), dim3(512), smem, st, p);
-  else hipLaunchKernelGGL((k_epi_attn_mfma<NT, 0>), dim3((unsigned)nblk), dim3(512), smem, st, p);
+  if (n1 == 5) hipLaunchKernelGGL((k_epi_attn_mfma<NT, 5>), dim3((unsigned)nblk), dim3(EA_HB * 128), smem, st, p);
+  else hipLaunchKernelGGL((k_epi_attn_mfma<NT, 0>), dim3((unsigned)nblk), dim3(EA_HB * 128), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }

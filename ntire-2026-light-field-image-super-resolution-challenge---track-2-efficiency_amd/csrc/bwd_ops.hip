@@ -292,30 +292,55 @@ int lfsr_epi0_dgrad_launch(const float* dE, const float* w_direct, float* dx, in
 
 // ---- AngConv.0 data gradient, streaming form -------------------------------------------------------------------------------------------------
 // dX[b, view, y, x][c] += sum_n dA[b, y, x][n] * W[view][n][c]   (the adjoint of the A x A, stride-A conv over the MacPI: DistgSSR.py:84-90).  K is only 16, so this
-// is a read-modify-write stream over dX (25 views x 64 channels per LR pixel) with 16 FMAs per element: plain VALU, 16 B per lane, the view's 16 x 64 weights in LDS,
-// the pixel's 16 gradient values from L1 -- no MFMA, no gather-GEMM.  Block = one (b, view) image, 16 pixels x 16 channel quads per pass.
+// is a read-modify-write stream over dX (25 views x 64 channels per LR pixel) with 16 FMAs per element: plain VALU, 16 B per lane, no MFMA, no gather-GEMM.
+// Block = one (b, view) image chunk, 16 pixels x 16 channel quads per pass.  Round 4: the thread's 16 x 4 weights live in registers for the block's life (they were
+// sixteen LDS reads per pixel) and FOUR pixels are in flight per thread -- their read-modify-write loads and gradient rows all issued before the first FMA -- where the
+// round-3 kernel kept one load -> 64 FMA -> store chain per thread and paid a memory round trip per pixel (114 us for a 105-MB stream whose floor is ~25 us).
+// Same FMA order per element (n = 0..15 onto the old value): bit-equal to the round-3 kernel.
 __global__ __launch_bounds__(256) void k_ang0_dgrad(const float* __restrict__ dA, const float* __restrict__ Wd, float* __restrict__ dX, int dx_stride, int dx_choff,
                                                     int AA, int HW, int chunks) {
-  __shared__ __attribute__((aligned(16))) float sWv[16 * 64];
   const int tid = threadIdx.x, c4 = tid & 15, pr = tid >> 4;
   const int img = blockIdx.x / chunks, chunk = blockIdx.x - img * chunks;   // img = b * AA + view
   const int b = img / AA, view = img - b * AA;
-  // direct pack [tap = view][Npad = 32][64]: rows n < 16
-  for (int i = tid; i < 16 * 16; i += 256) *reinterpret_cast<float4*>(sWv + i * 4) = *reinterpret_cast<const float4*>(Wd + ((long long)view * 32 + (i >> 4)) * 64 + (i & 15) * 4);
-  __syncthreads();
+  float4 wv[16];   // direct pack [tap = view][Npad = 32][64]: rows n < 16, this thread's channel quad
+#pragma unroll
+  for (int n = 0; n < 16; ++n) wv[n] = *reinterpret_cast<const float4*>(Wd + ((long long)view * 32 + n) * 64 + c4 * 4);
   const int per = (HW + chunks - 1) / chunks;
   const int p0 = chunk * per, p1 = p0 + per < HW ? p0 + per : HW;
-  for (int px = p0 + pr; px < p1; px += 16) {
-    const float4* ga = reinterpret_cast<const float4*>(dA + ((long long)b * HW + px) * 16);
-    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2], g3 = ga[3];
-    float4* dst = reinterpret_cast<float4*>(dX + ((long long)img * HW + px) * dx_stride + dx_choff + c4 * 4);
-    float4 acc = *dst;
-    const float gv[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+  constexpr int U = 4;
+  auto fma16 = [&](float4& acc, const float4 (&g)[4]) {
+    const float gv[16] = {g[0].x, g[0].y, g[0].z, g[0].w, g[1].x, g[1].y, g[1].z, g[1].w, g[2].x, g[2].y, g[2].z, g[2].w, g[3].x, g[3].y, g[3].z, g[3].w};
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
-      const float4 wv = *reinterpret_cast<const float4*>(sWv + n * 64 + c4 * 4);
-      acc.x = fmaf(gv[n], wv.x, acc.x); acc.y = fmaf(gv[n], wv.y, acc.y); acc.z = fmaf(gv[n], wv.z, acc.z); acc.w = fmaf(gv[n], wv.w, acc.w);
+      acc.x = fmaf(gv[n], wv[n].x, acc.x); acc.y = fmaf(gv[n], wv[n].y, acc.y);
+      acc.z = fmaf(gv[n], wv[n].z, acc.z); acc.w = fmaf(gv[n], wv[n].w, acc.w);
     }
+  };
+  int q0 = p0;
+  for (; q0 + 16 * U <= p1; q0 += 16 * U) {       // whole groups of 64 pixels (a block-uniform trip count): no control flow between the loads and the stores
+    float4 acc[U], g[U][4];
+    float4* dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int px = q0 + pr + 16 * u;
+      dst[u] = reinterpret_cast<float4*>(dX + ((long long)img * HW + px) * dx_stride + dx_choff + c4 * 4);
+      acc[u] = *dst[u];
+      const float4* ga = reinterpret_cast<const float4*>(dA + ((long long)b * HW + px) * 16);
+      g[u][0] = ga[0]; g[u][1] = ga[1]; g[u][2] = ga[2]; g[u][3] = ga[3];
+    }
+    __builtin_amdgcn_sched_barrier(0);            // (every load of the group is in flight before the first FMA: the scheduler otherwise sinks them between the pixels)
+#pragma unroll
+    for (int u = 0; u < U; ++u) fma16(acc[u], g[u]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) *dst[u] = acc[u];
+  }
+  for (int px = q0 + pr; px < p1; px += 16) {      // ragged rest (< 64 pixels)
+    float4* dst = reinterpret_cast<float4*>(dX + ((long long)img * HW + px) * dx_stride + dx_choff + c4 * 4);
+    float4 acc = *dst;
+    const float4* ga = reinterpret_cast<const float4*>(dA + ((long long)b * HW + px) * 16);
+    const float4 g[4] = {ga[0], ga[1], ga[2], ga[3]};
+    fma16(acc, g);
     *dst = acc;
   }
 }
