@@ -615,7 +615,7 @@ def bench_infer(args, rank, world, dev, dist):
                  "k_conv3x3_wino (Winograd F(2x2,3x3), 16 position-GEMMs on fp32 MFMA 32x32x2)" if wino2 else
                  "k_conv3x3_wino4 (per-view 3x3 64->64 in Winograd F(4x4,3x3) form: 36 position-GEMMs per 8x32-pixel tile on fp32 MFMA 16x16x4)")
         traffic, tsrc = None, None
-        for cand in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_conv3x3.json"):
+        for cand in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_conv3x3.json"):
             pmc = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc):
                 j = json.load(open(pmc))
