@@ -18,6 +18,11 @@
 // MI355X_MICROARCH.md, LDS): K chunk c of token t at (c + ((t >> 2) & 2)) & 3, V^T chunk j of row d at j ^ ((-(d >> 2)) & 3).  The round-2 rotations (by
 // t >> 2 and by 4 d) were conflict-free for CONTIGUOUS groups of 16 lanes and two-way conflicted on the real ones (SQ_LDS_BANK_CONFLICT 39 % of the
 // LDS-active cycles, profiles/r03_logs/pmc_epit_sq_summary.json).
+// Round 4, measured and NOT adopted (profiles/r04_logs/c12_*, c14_*; one process each, 134-136 us for this kernel at B = 8): the conflict-free layouts themselves are
+// worth 1 %; two / one head(s) per block (256 / 128 threads) are 3 % / 8 % slower; the three-term bf16 form (K, V split once at staging into bf16 planes, Q once per
+// tile, P per key tile; two of the six products per v_mfma_f32_16x16x32_bf16) is bit-for-bit as accurate (1.7e-6 from this kernel) and 19-29 % SLOWER (162-175 us):
+// per (query tile, key tile) pair the kernel issues ~28 VALU instructions beside 8 fp32 MFMAs -- mask, running maximum, exponentials -- and the split of P adds 14
+// more while the matrix work it saves was not what the pair waits for.
 #include <math.h>
 
 #include "lfsr_internal.h"
@@ -39,25 +44,22 @@ struct EpiAttnArgs {
   int L;           // n1 * n2
 };
 
-#ifndef EA_HB
-#define EA_HB 4     // heads per block (two waves each): 4 -> 512 threads and 80 KB of LDS, 2 -> 256 threads and 40 KB
-#endif
 template <int NT, int N1>      // N1: the angular resolution when known at compile time (5: the BASELINE geometry; divisions by it become multiplies), 0: read from the arguments
-__global__ __launch_bounds__(EA_HB * 128) void k_epi_attn_mfma(EpiAttnArgs p) {
+__global__ __launch_bounds__(512) void k_epi_attn_mfma(EpiAttnArgs p) {
   const int n1 = N1 ? N1 : p.n1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LR = NT * 16;                 // padded sequence length
   constexpr int HEAD_FLOATS = LR * 16 * 2;    // K [LR][16] + V^T [16][LR]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h4 = wave >> 1, half = wave & 1, l15 = lane & 15, g = lane >> 4;
-  const int hblocks = p.nheads / EA_HB;
+  const int hblocks = p.nheads >> 2;
   const int hq = blockIdx.x % hblocks;
   int t = blockIdx.x / hblocks;
   const int s2 = t % p.ns2; t /= p.ns2;
   const int s1 = t % p.ns1;
   const int s0 = t / p.ns1;
   const long long base = s0 * p.bs0 + s1 * p.bs1 + s2 * p.bs2;
-  const int head = hq * EA_HB + h4;
+  const int head = hq * 4 + h4;
   float* const sK = smem + h4 * HEAD_FLOATS;
   float* const sVt = sK + LR * 16;
 
@@ -176,7 +178,7 @@ int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
                               float* o, int o_stride, int o_choff, int nheads, int ns0, int ns1, int ns2, long long bs0, long long bs1, long long bs2,
                               int n1, int n2, long long st1, long long st2, int l1, int r1, int l2, int r2, int clip2, hipStream_t st) {
   const int L = n1 * n2;
-  if (nheads % EA_HB || L > 160 || L < 1 || l1 < n1 - 1 || r1 < n1) return LFSR_E_ARG;    // every angular position visible; <= 10 tiles of 16 tokens
+  if (nheads % 4 || L > 160 || L < 1 || l1 < n1 - 1 || r1 < n1) return LFSR_E_ARG;    // every angular position visible; <= 10 tiles of 16 tokens
   EpiAttnArgs p{};
   p.Q = q; p.q_stride = q_stride; p.q_choff = q_choff; p.K = k; p.k_stride = k_stride; p.k_choff = k_choff;
   p.V = v; p.v_stride = v_stride; p.v_choff = v_choff; p.O = o; p.o_stride = o_stride; p.o_choff = o_choff;
@@ -184,10 +186,10 @@ int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
   p.n1 = n1; p.n2 = n2; p.st1 = st1; p.st2 = st2; p.l2 = l2; p.r2 = r2; p.clip2 = clip2 > 0 ? clip2 : n2;
   p.scale = (1.0f / sqrtf(16.0f)) * 1.44269504088896340736f;
   p.L = L;
-  const long long nblk = (long long)ns0 * ns1 * ns2 * (nheads / EA_HB);
+  const long long nblk = (long long)ns0 * ns1 * ns2 * (nheads / 4);
   if (nblk <= 0 || nblk > 0x7fffffffLL) return LFSR_E_ARG;
   constexpr int NT = 10;
-  const int smem = EA_HB * NT * 16 * 16 * 2 * 4;   // 81920 at four heads per block
+  const int smem = 4 * NT * 16 * 16 * 2 * 4;   // 81920
   static std::atomic<bool> attr_set[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return LFSR_E_ARG;
@@ -197,8 +199,8 @@ int lfsr_epi_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
     if (e != hipSuccess) return LFSR_HIP_ERR(e);
     attr_set[dev] = true;
   }
-  if (n1 == 5) hipLaunchKernelGGL((k_epi_attn_mfma<NT, 5>), dim3((unsigned)nblk), dim3(EA_HB * 128), smem, st, p);
-  else hipLaunchKernelGGL((k_epi_attn_mfma<NT, 0>), dim3((unsigned)nblk), dim3(EA_HB * 128), smem, st, p);
+  if (n1 == 5) hipLaunchKernelGGL((k_epi_attn_mfma<NT, 5>), dim3((unsigned)nblk), dim3(512), smem, st, p);
+  else hipLaunchKernelGGL((k_epi_attn_mfma<NT, 0>), dim3((unsigned)nblk), dim3(512), smem, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
