@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
 
 // ---- init_conv (Cin = 1) fused with SAI2MacPI -----------------------------------------------------
 // 16 threads per output pixel, 4 output channels each -> one 256-B coalesced store per pixel.
+// IDX: the type the (b, view, y, x) decode runs in: unsigned when the launch has < 2^31 work items (one 32-bit division sequence per axis instead of a 64-bit one:
+// the round-3 kernel spent more instructions on its four 64-bit div / mod than on its 36 FMAs), long long otherwise.  Addresses stay 64-bit.
+template <typename IDX>
 __global__ __launch_bounds__(256) void k_initconv(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int y_stride, int y_choff,
                                                   int B, int A, int h, int wd) {
   const long long npix = (long long)B * A * A * h * wd;
@@ -63,14 +66,15 @@ __global__ __launch_bounds__(256) void k_initconv(const float* __restrict__ x, c
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int k = 0; k < 9; ++k) wr[i][k] = w[(c4 + i) * 9 + k];
-  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < npix * 16; g += (long long)gridDim.x * 256) {
-    long long pix = g >> 4;
-    int xx = (int)(pix % wd);
-    long long t = pix / wd;
-    int yy = (int)(t % h);
-    t /= h;
-    int view = (int)(t % (A * A));
-    int b = (int)(t / (A * A));
+  for (IDX g = (IDX)blockIdx.x * 256 + threadIdx.x; g < (IDX)(npix * 16); g += (IDX)gridDim.x * 256) {
+    const IDX pixi = g >> 4;
+    const long long pix = (long long)pixi;
+    int xx = (int)(pixi % (IDX)wd);
+    IDX t = pixi / (IDX)wd;
+    int yy = (int)(t % (IDX)h);
+    t /= (IDX)h;
+    int view = (int)(t % (IDX)(A * A));
+    int b = (int)(t / (IDX)(A * A));
     int u = view / A, v = view - u * A;
     const float* img = x + (long long)b * Hm * Wm + (long long)(u * h) * Wm + v * wd;  // this view's top-left in the mosaic
     float xv[9];
@@ -110,8 +114,70 @@ __global__ void k_fold_head(const float* __restrict__ w0, const float* __restric
   }
 }
 
+// s = 4, w % 4 == 0: SIXTEEN LANES PER LR PIXEL, one output each.  A wave stages 16 consecutive pixels (4 KB, one coalesced 16-B load per lane and group of four) in a
+// wave-private LDS tile; lane (pixel p, output o = 4 i + j) then reads its pixel's 64 channels as sixteen ds_read_b128 (the 16 lanes of a pixel read the same address: a
+// broadcast) against the 64 weights of ITS output row, which it keeps in registers -- the same fma chain over k = 0..63 as the one-thread-per-(pixel, sub-row) form below,
+// so the same bits -- adds bias and the bilinear skip and stores one dword (16 B contiguous per pixel and sub-row).  The older form reads 16 B per lane at a 256-B lane
+// stride, every pixel four times (105 us for 265 MB); a first 16-lane form that split the CHANNELS over the lanes and summed 16 x 16 partials through LDS was LDS-bound (95 us).
+__global__ __launch_bounds__(256) void k_head4_lanes(const float* __restrict__ f, int f_stride, int f_choff, const float* __restrict__ wf, const float* __restrict__ bf,
+                                                     const float* __restrict__ xlr, float* __restrict__ out, int B, int A, int h, int w) {
+  constexpr int U = 4;                                                       // groups of four pixels per wave and pass
+  __shared__ __attribute__((aligned(16))) float st[4][U * 4 * 64];          // [wave][group][pixel][channel]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, pq = lane >> 4, l = lane & 15;
+  const int Hm = A * h, Wm = A * w, Ho = Hm * 4, Wo = Wm * 4;
+  const unsigned npix = (unsigned)B * A * A * h * w;
+  float4 wreg[16];        // the 64 weights of this lane's output row o = l
+#pragma unroll
+  for (int k = 0; k < 16; ++k) wreg[k] = *reinterpret_cast<const float4*>(wf + l * 64 + 4 * k);
+  const float bias = bf[l];
+  float* tile = st[wave];
+  const int i = l >> 2, j = l & 3;
+  for (unsigned base0 = (blockIdx.x * 4u + wave) * (4u * U); base0 < npix; base0 += gridDim.x * (16u * U)) {
+    float4 fv[U];
+#pragma unroll
+    for (int g = 0; g < U; ++g) {
+      const unsigned pix = base0 + 4u * g + pq;
+      fv[g] = pix < npix ? *reinterpret_cast<const float4*>(f + (size_t)pix * f_stride + f_choff + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int g = 0; g < U; ++g) *reinterpret_cast<float4*>(tile + (g * 4 + pq) * 64 + 4 * l) = fv[g];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < U; ++g) {
+      const unsigned base = base0 + 4u * g;           // four consecutive pixels (w % 4 == 0: one image row)
+      if (base >= npix) break;
+      const float* fp = tile + (g * 4 + pq) * 64;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(fp + 4 * k);
+        acc = fmaf(q.x, wreg[k].x, acc); acc = fmaf(q.y, wreg[k].y, acc); acc = fmaf(q.z, wreg[k].z, acc); acc = fmaf(q.w, wreg[k].w, acc);
+      }
+      // (b, view, y, x) of the group's first pixel: wave-uniform
+      const unsigned x0 = base % (unsigned)w; unsigned t = base / (unsigned)w;
+      const unsigned y = t % (unsigned)h; t /= (unsigned)h;
+      const unsigned view = t % (unsigned)(A * A), b = t / (unsigned)(A * A);
+      const int u = (int)view / A, v = (int)view - u * A, x = (int)x0 + pq;
+      // bilinear skip on the whole mosaic (F.interpolate align_corners=False, DistgSSR.py:30)
+      const int Y = (u * h + (int)y) * 4 + i, X = (v * w + x) * 4 + j;
+      float sy = fmaxf(((float)Y + 0.5f) * 0.25f - 0.5f, 0.f);
+      int y0 = (int)sy; if (y0 > Hm - 1) y0 = Hm - 1;
+      const int y1 = y0 + 1 < Hm ? y0 + 1 : Hm - 1;
+      const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+      float sx = fmaxf(((float)X + 0.5f) * 0.25f - 0.5f, 0.f);
+      int xx0 = (int)sx; if (xx0 > Wm - 1) xx0 = Wm - 1;
+      const int xx1 = xx0 + 1 < Wm ? xx0 + 1 : Wm - 1;
+      const float lx1 = sx - (float)xx0, lx0 = 1.f - lx1;
+      const float* xb = xlr + (size_t)b * Hm * Wm;
+      const float up = ly0 * (lx0 * xb[(size_t)y0 * Wm + xx0] + lx1 * xb[(size_t)y0 * Wm + xx1]) + ly1 * (lx0 * xb[(size_t)y1 * Wm + xx0] + lx1 * xb[(size_t)y1 * Wm + xx1]);
+      out[((size_t)b * Ho + Y) * Wo + X] = acc + bias + up;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // one thread per (LR pixel, sub-row i): s outputs along j, stored contiguously in the HR mosaic
-template <int S>
+template <int S, typename IDX>      // IDX: as in k_initconv
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ f, int f_stride, int f_choff, const float* __restrict__ wf, const float* __restrict__ bf,
                                              const float* __restrict__ xlr, float* __restrict__ out, int B, int A, int h, int w) {
   __shared__ float sw[S * S * 64];
@@ -122,15 +188,15 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ f, int f
   const int Hm = A * h, Wm = A * w, Ho = Hm * S, Wo = Wm * S;
   const long long total = (long long)B * A * A * h * S * w;   // (b, view, y, i, x)
   const float rs = 1.0f / (float)S;
-  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
-    int x = (int)(g % w);
-    long long t = g / w;
-    int i = (int)(t % S);
-    t /= S;
-    int y = (int)(t % h);
-    t /= h;
-    int view = (int)(t % (A * A));
-    int b = (int)(t / (A * A));
+  for (IDX g = (IDX)blockIdx.x * 256 + threadIdx.x; g < (IDX)total; g += (IDX)gridDim.x * 256) {
+    int x = (int)(g % (IDX)w);
+    IDX t = g / (IDX)w;
+    int i = (int)(t % (IDX)S);
+    t /= (IDX)S;
+    int y = (int)(t % (IDX)h);
+    t /= (IDX)h;
+    int view = (int)(t % (IDX)(A * A));
+    int b = (int)(t / (IDX)(A * A));
     int u = view / A, v = view - u * A;
     long long pix = (((long long)b * A * A + view) * h + y) * w + x;
     const float4* fp = reinterpret_cast<const float4*>(f + pix * f_stride + f_choff);
@@ -337,7 +403,8 @@ int lfsr_initconv_fwd(const float* x, const float* w, float* y, int y_stride, in
   long long total = (long long)B * A * A * h * wd * 16;
   unsigned grid = lfsr_blocks(total, 256);
   if (grid > 256u * 16) grid = 256u * 16;
-  hipLaunchKernelGGL(k_initconv, dim3(grid), dim3(256), 0, lfsr_stream(stream), x, w, y, y_stride, y_choff, B, A, h, wd);
+  if (total < (1LL << 31)) hipLaunchKernelGGL(k_initconv<unsigned>, dim3(grid), dim3(256), 0, lfsr_stream(stream), x, w, y, y_stride, y_choff, B, A, h, wd);
+  else hipLaunchKernelGGL(k_initconv<long long>, dim3(grid), dim3(256), 0, lfsr_stream(stream), x, w, y, y_stride, y_choff, B, A, h, wd);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }
@@ -358,12 +425,24 @@ int lfsr_upsample_head_fwd(const float* f, int f_stride, int f_choff, const floa
   unsigned grid = lfsr_blocks(total, 256);
   if (grid > 256u * 16) grid = 256u * 16;
   hipStream_t st = lfsr_stream(stream);
+  const bool i32 = total < (1LL << 31);
+  if (s == 4 && w % 4 == 0 && i32 && !(((uintptr_t)f | (uintptr_t)wf) & 15)) {      // the x4 model: sixteen lanes per pixel
+    const long long npix = (long long)B * A * A * h * w;
+    unsigned g4 = lfsr_blocks(npix, 64);
+    if (g4 > 256u * 8) g4 = 256u * 8;
+    hipLaunchKernelGGL(k_head4_lanes, dim3(g4), dim3(256), 0, st, f, f_stride, f_choff, wf, bf, x_lr, out, B, A, h, w);
+    LFSR_CHECK_LAUNCH();
+    return LFSR_OK;
+  }
+#define HEAD_GO(SS) do { if (i32) hipLaunchKernelGGL((k_head<SS, unsigned>), dim3(grid), dim3(256), 0, st, f, f_stride, f_choff, wf, bf, x_lr, out, B, A, h, w); \
+                         else hipLaunchKernelGGL((k_head<SS, long long>), dim3(grid), dim3(256), 0, st, f, f_stride, f_choff, wf, bf, x_lr, out, B, A, h, w); } while (0)
   switch (s) {
-    case 2: hipLaunchKernelGGL((k_head<2>), dim3(grid), dim3(256), 0, st, f, f_stride, f_choff, wf, bf, x_lr, out, B, A, h, w); break;
-    case 3: hipLaunchKernelGGL((k_head<3>), dim3(grid), dim3(256), 0, st, f, f_stride, f_choff, wf, bf, x_lr, out, B, A, h, w); break;
-    case 4: hipLaunchKernelGGL((k_head<4>), dim3(grid), dim3(256), 0, st, f, f_stride, f_choff, wf, bf, x_lr, out, B, A, h, w); break;
+    case 2: HEAD_GO(2); break;
+    case 3: HEAD_GO(3); break;
+    case 4: HEAD_GO(4); break;
     default: return LFSR_E_ARG;
   }
+#undef HEAD_GO
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
 }

@@ -139,6 +139,31 @@ __global__ __launch_bounds__(256) void k_pixel_shuffle2d_vec(const float* __rest
   }
 }
 
+// ---- a3 for r = 4 (the x4 model) and r = 2, 4-byte elements, < 2^31 elements: one thread = ONE input position (b c, y, x) and all r*r planes.  A lane's r*r dword
+// loads are coalesced across the wave (consecutive x: 256 B per instruction and plane) and all in flight before the first store; its r stores are r floats each of r
+// different output rows, and CONSECUTIVE LANES STORE CONSECUTIVE 16-B (r = 4) PIECES: 1 KB contiguous per store instruction.  The round-1 form (4 consecutive x per
+// thread, 16-B loads) stored 16 B per lane at a 64-B lane stride -- every store instruction touched 64 partial 64-B segments -- and paid three 64-bit divisions per
+// thread; 32-bit index arithmetic here.
+template <int R>
+__global__ __launch_bounds__(256) void k_pixel_shuffle2d_x(const float* __restrict__ in, float* __restrict__ out, unsigned total, unsigned H, unsigned W) {
+  const unsigned HW = H * W;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned bc = idx / HW, rem = idx - bc * HW, y = rem / W, x = rem - y * W;
+    const float* src = in + (size_t)bc * (R * R) * HW + rem;
+    float v[R][R];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[i][j] = src[(size_t)(i * R + j) * HW];
+    float* dst = out + ((size_t)bc * H * R + (size_t)y * R) * ((size_t)W * R) + (size_t)x * R;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      if (R == 4) *reinterpret_cast<float4*>(dst + (size_t)i * W * R) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+      else *reinterpret_cast<float2*>(dst + (size_t)i * W * R) = make_float2(v[i][0], v[i][1]);
+    }
+  }
+}
+
 // ---- a3: out[b,c,y*r+i,x*r+j] = in[b,c*r*r+i*r+j,y,x] ------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_pixel_shuffle2d(const T* __restrict__ in, T* __restrict__ out, int BC, int r, int H, int W) {
@@ -387,6 +412,15 @@ int lfsr_pixel_shuffle2d(const void* in, void* out, int B, int C, int r, int H, 
   long long total = (long long)B * C * H * r * W * r;
   if (total == 0) return LFSR_OK;
   if (!in || !out) return LFSR_E_ARG;
+  if (elem_bytes == 4 && (r == 4 || r == 2) && total < (1LL << 31) && !(((uintptr_t)in | (uintptr_t)out) & 15) && ((long long)W * r * 4) % (r == 4 ? 16 : 8) == 0) {
+    const unsigned npos = (unsigned)((long long)B * C * H * W);
+    unsigned grid = grid_for(npos);
+    hipStream_t st = lfsr_stream(stream);
+    if (r == 4) hipLaunchKernelGGL((k_pixel_shuffle2d_x<4>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, npos, (unsigned)H, (unsigned)W);
+    else hipLaunchKernelGGL((k_pixel_shuffle2d_x<2>), dim3(grid), dim3(256), 0, st, (const float*)in, (float*)out, npos, (unsigned)H, (unsigned)W);
+    LFSR_CHECK_LAUNCH();
+    return LFSR_OK;
+  }
   if (elem_bytes == 4 && W % 4 == 0 && r >= 2 && r <= 5 && !(((uintptr_t)in | (uintptr_t)out) & 15)) {
     long long work = (long long)B * C * H * r * (W / 4);
     unsigned grid = grid_for(work);
