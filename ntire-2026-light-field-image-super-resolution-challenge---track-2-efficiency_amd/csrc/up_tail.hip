@@ -350,12 +350,17 @@ __global__ __launch_bounds__(512) void k_up_tail2(UpTailArgs p) {
       for (int py = 0; py < S + 2; ++py) {
         const int dy = py == 0 ? -1 : py == S + 1 ? 1 : 0, sy = py == 0 ? S - 1 : py == S + 1 ? 0 : py - 1;
         const float* ur = uc + dy * PW * LDS_ROW + sy * S;
-        P[py][0] = ur[-LDS_ROW + S - 1];
-        P[py][S + 1] = ur[LDS_ROW];
         if constexpr (S == 4) {
+          // the two halo columns come as the neighbours' whole 16-B quads: as dword reads (element 3 of the left pixel's quad, element 0 of the right one's) the 32 lanes
+          // of a group hit only the 8 banks = 3 (or 0) mod 4 -- four-way conflicts on 12 of a thread's 18 reads per channel (SQ_LDS_BANK_CONFLICT 44 % of this kernel's
+          // LDS-active cycles, LDS busy half of the launch: profiles/r04_logs/pmc_lds_*); the 16-B reads are conflict-free for the hardware's lane groups
+          const float4 mL = *reinterpret_cast<const float4*>(ur - LDS_ROW);
           const float4 m = *reinterpret_cast<const float4*>(ur);
-          P[py][1] = m.x; P[py][2] = m.y; P[py][3] = m.z; P[py][4] = m.w;
+          const float4 mR = *reinterpret_cast<const float4*>(ur + LDS_ROW);
+          P[py][0] = mL.w; P[py][1] = m.x; P[py][2] = m.y; P[py][3] = m.z; P[py][4] = m.w; P[py][5] = mR.x;
         } else {
+          P[py][0] = ur[-LDS_ROW + S - 1];
+          P[py][S + 1] = ur[LDS_ROW];
           const float2 m = *reinterpret_cast<const float2*>(ur);
           P[py][1] = m.x; P[py][2] = m.y;
         }
@@ -512,12 +517,17 @@ __global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
       for (int py = 0; py < S + 2; ++py) {
         const int dy = py == 0 ? -1 : py == S + 1 ? 1 : 0, sy = py == 0 ? S - 1 : py == S + 1 ? 0 : py - 1;
         const float* ur = uc + dy * PW * LDS_ROW + sy * S;
-        P[py][0] = ur[-LDS_ROW + S - 1];
-        P[py][S + 1] = ur[LDS_ROW];
         if constexpr (S == 4) {
+          // the two halo columns come as the neighbours' whole 16-B quads: as dword reads (element 3 of the left pixel's quad, element 0 of the right one's) the 32 lanes
+          // of a group hit only the 8 banks = 3 (or 0) mod 4 -- four-way conflicts on 12 of a thread's 18 reads per channel (SQ_LDS_BANK_CONFLICT 44 % of this kernel's
+          // LDS-active cycles, LDS busy half of the launch: profiles/r04_logs/pmc_lds_*); the 16-B reads are conflict-free for the hardware's lane groups
+          const float4 mL = *reinterpret_cast<const float4*>(ur - LDS_ROW);
           const float4 m = *reinterpret_cast<const float4*>(ur);
-          P[py][1] = m.x; P[py][2] = m.y; P[py][3] = m.z; P[py][4] = m.w;
+          const float4 mR = *reinterpret_cast<const float4*>(ur + LDS_ROW);
+          P[py][0] = mL.w; P[py][1] = m.x; P[py][2] = m.y; P[py][3] = m.z; P[py][4] = m.w; P[py][5] = mR.x;
         } else {
+          P[py][0] = ur[-LDS_ROW + S - 1];
+          P[py][S + 1] = ur[LDS_ROW];
           const float2 m = *reinterpret_cast<const float2*>(ur);
           P[py][1] = m.x; P[py][2] = m.y;
         }
