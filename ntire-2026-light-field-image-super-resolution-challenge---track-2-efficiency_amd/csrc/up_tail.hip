@@ -552,6 +552,170 @@ __global__ __launch_bounds__(512) void k_up_tail3(UpTailArgs p) {
   ut_tail_store<S>(p, oacc, dcg, b, Y0 + ply - 1, X0 + plx - 1, Hm, Wm);
 }
 
+// ---- fourth form (default at s = 4, round 4): the third form with its two phases OVERLAPPED -----------------------------------------------------------------
+// k_up_tail3 runs, per chunk of four channels, the 1x1 conv on the matrix pipe (all waves) -> barrier -> the gathered 3x3 HR conv on the VALU (all waves) -> barrier:
+// the matrix pipe is busy 27 % of the launch, the VALU phase 40 %, one after the other.  Here the U chunk is double-buffered and one barrier interval holds the VALU
+// phase of chunk cc AND the matrix phase of chunk cc + 1; waves 0..3 take the matrix phase first, waves 4..7 the VALU phase first (wave w and w + 4 share a SIMD), so on
+// every SIMD one wave's bf16 MFMAs run beside the other wave's FMAs.  One barrier per chunk instead of two.  To fit two U buffers beside the double-buffered weight
+// planes the U rows lose their 16-B padding (64 floats): the sixteen 16-B pieces of row r sit at piece ^ (r & 15), which keeps the matrix phase's 16-B stores and the
+// gather's 16-B reads (own pixel and both neighbours) conflict-free for the lane groups the hardware serves together; a thread's 18 read offsets are constants of the
+// launch.  Same arithmetic in the same order as k_up_tail3: bit-equal.
+constexpr int UR4 = 64;
+
+__global__ __launch_bounds__(512) void k_up_tail4(UpTailArgs p) {
+  constexpr int S = 4, S2 = 16, CC = 4, NCH = 16;
+  constexpr int PW = UT_X + 2;
+  constexpr int WPL = 64 * 64;
+  extern __shared__ __attribute__((aligned(16))) float smu[];
+  float* sU0 = smu;                                   // [2][UT2_ROWS][UR4]
+  float* sW3 = smu + 2 * UT2_ROWS * UR4;              // [64][9]
+  unsigned short* sWb = reinterpret_cast<unsigned short*>(sW3 + 64 * 9);   // [2][3 planes][8 (K step, k-group)][64 rows][8]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int Hm = p.A * p.h, Wm = p.A * p.w, HW = p.h * p.w;
+  int t = blockIdx.x;
+  const int tx = t % p.tiles_x; t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int b = t / p.tiles_y;
+  const int Y0 = ty * UT_Y, X0 = tx * UT_X;
+
+  for (int i = tid; i < 64 * 9; i += 512) sW3[i] = p.W3[i];
+  const int wr = tid >> 3, wk = tid & 7;
+  auto wsrc = [&](int cc) -> const float* { int dc = wr / S2, ij = wr - dc * S2; return p.W0p + ((long long)(ij * 64 + cc * CC + dc)) * 64 + wk * 8; };
+  float4 rw[2];
+  auto fetch_w = [&](int cc) { const float* s0 = wsrc(cc); rw[0] = *reinterpret_cast<const float4*>(s0); rw[1] = *reinterpret_cast<const float4*>(s0 + 4); };
+  auto store_w = [&](int bufi) {
+    u32x4u p0, p1, p2;
+    ut_split8(rw[0], rw[1], p0, p1, p2);
+    unsigned short* d = sWb + bufi * 3 * WPL + (wk * 64 + wr) * 8;
+    *reinterpret_cast<u32x4u*>(d) = p0; *reinterpret_cast<u32x4u*>(d + WPL) = p1; *reinterpret_cast<u32x4u*>(d + 2 * WPL) = p2;
+  };
+  fetch_w(0);
+
+  u32x4u f0[4][2], f1[4][2], f2[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = wave + 8 * i;
+    const int px = (u >> 1) * 16 + l15;
+    float4 v[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { v[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); v[s][1] = v[s][0]; }
+    if (u < 26 && px < UT_PIX) {
+      const int ly = px / PW, lx = px - ly * PW;
+      const int Ym = Y0 + ly - 1, Xm = X0 + lx - 1;
+      if (Ym >= 0 && Ym < Hm && Xm >= 0 && Xm < Wm) {
+        const int uu = Ym / p.h, y = Ym - uu * p.h, vv = Xm / p.w, x = Xm - vv * p.w;
+        const long long pix = ((long long)b * p.A * p.A + uu * p.A + vv) * HW + (long long)y * p.w + x;
+        const float* src = p.F + pix * p.f_stride + p.f_choff + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { v[s][0] = *reinterpret_cast<const float4*>(src + 32 * s); v[s][1] = *reinterpret_cast<const float4*>(src + 32 * s + 4); }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) ut_split8(v[s][0], v[s][1], f0[i][s], f1[i][s], f2[i][s]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) asm volatile("s_nop 4" : "+v"(f0[i][s]), "+v"(f1[i][s]), "+v"(f2[i][s]));
+  }
+  store_w(0);
+  __syncthreads();
+
+  // ---- the gather's constants: thread (LR pixel pp, channel dcg of the chunk); row r of U = halo pixel (ply + dy) * PW + plx + dx; piece = dcg * 4 + sy
+  const int dcg = tid & 3, pp = tid >> 2;
+  const int ply = 1 + pp / UT_X, plx = 1 + pp % UT_X;
+  int offL[S + 2], offC[S + 2], offR[S + 2];
+#pragma unroll
+  for (int py = 0; py < S + 2; ++py) {
+    const int dy = py == 0 ? -1 : py == S + 1 ? 1 : 0, sy = py == 0 ? S - 1 : py == S + 1 ? 0 : py - 1;
+    const int rc = (ply + dy) * PW + plx, piece = dcg * 4 + sy;
+    offL[py] = (rc - 1) * UR4 + ((piece ^ ((rc - 1) & 15)) << 2);
+    offC[py] = rc * UR4 + ((piece ^ (rc & 15)) << 2);
+    offR[py] = (rc + 1) * UR4 + ((piece ^ ((rc + 1) & 15)) << 2);
+  }
+  float oacc[S2];
+#pragma unroll
+  for (int i = 0; i < S2; ++i) oacc[i] = 0.f;
+
+  // (1) U[px][n] of chunk cc -> sUb: D[weight row n][pixel]: lane (pixel l15, g) receives columns n = 16 ct + 4 g + r of its pixel; LeakyReLU; one 16-B store
+  auto phase_mfma = [&](int cc, float* sUb) {
+    const unsigned short* sWc = sWb + (cc & 1) * 3 * WPL;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int u = wave + 8 * i;
+      if (u < 26) {
+        const int rt = u >> 1, ch = u & 1;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const int ct = 2 * ch + c2;
+          f32x4u acc = {0.f, 0.f, 0.f, 0.f};
+          asm volatile("s_nop 1" : "+v"(acc));
+          const unsigned short* wq = sWc + (g * 64 + ct * 16 + l15) * 8;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const u32x4u w0 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s);
+            const u32x4u w1 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s + WPL);
+            const u32x4u w2 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s + 2 * WPL);
+            ut_mfma(acc, w2, f0[i][s]); ut_mfma(acc, w0, f2[i][s]); ut_mfma(acc, w1, f1[i][s]);
+            ut_mfma(acc, w1, f0[i][s]); ut_mfma(acc, w0, f1[i][s]); ut_mfma(acc, w0, f0[i][s]);
+          }
+          asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
+          float4 o;
+          o.x = acc[0] >= 0.f ? acc[0] : acc[0] * p.slope; o.y = acc[1] >= 0.f ? acc[1] : acc[1] * p.slope;
+          o.z = acc[2] >= 0.f ? acc[2] : acc[2] * p.slope; o.w = acc[3] >= 0.f ? acc[3] : acc[3] * p.slope;
+          *reinterpret_cast<float4*>(sUb + (rt * 16 + l15) * UR4 + ((((ct * 4 + g) ^ l15) & 15) << 2)) = o;      // row & 15 == l15
+        }
+      }
+    }
+  };
+  // (3) the 3x3 HR conv of chunk cc's channel dcg, gathered per LR pixel from sUb
+  auto phase_valu = [&](int cc, const float* sUb) {
+    float P[S + 2][S + 2];
+#pragma unroll
+    for (int py = 0; py < S + 2; ++py) {
+      const float4 mL = *reinterpret_cast<const float4*>(sUb + offL[py]);
+      const float4 m = *reinterpret_cast<const float4*>(sUb + offC[py]);
+      const float4 mR = *reinterpret_cast<const float4*>(sUb + offR[py]);
+      P[py][0] = mL.w; P[py][1] = m.x; P[py][2] = m.y; P[py][3] = m.z; P[py][4] = m.w; P[py][5] = mR.x;
+    }
+    float wv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wv[q] = sW3[(cc * CC + dcg) * 9 + q];
+#pragma unroll
+    for (int sy = 0; sy < S; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < S; ++sx) {
+        float a = oacc[sy * S + sx];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) a = fmaf(P[sy + ky][sx + kx], wv[ky * 3 + kx], a);
+        oacc[sy * S + sx] = a;
+      }
+  };
+
+  // prologue interval: the matrix phase of chunk 0; the weights of chunk 1
+  fetch_w(1);
+  phase_mfma(0, sU0);
+  store_w(1);
+  __syncthreads();
+  const bool mfma_first = wave < 4;
+#pragma unroll 1
+  for (int cc = 0; cc < NCH; ++cc) {
+    float* const sUc = sU0 + (cc & 1) * UT2_ROWS * UR4;
+    float* const sUn = sU0 + ((cc + 1) & 1) * UT2_ROWS * UR4;
+    if (cc + 2 < NCH) fetch_w(cc + 2);
+    if (mfma_first) {
+      if (cc + 1 < NCH) phase_mfma(cc + 1, sUn);
+      phase_valu(cc, sUc);
+    } else {
+      phase_valu(cc, sUc);
+      if (cc + 1 < NCH) phase_mfma(cc + 1, sUn);
+    }
+    if (cc + 2 < NCH) store_w(cc & 1);       // (the buffer of chunk cc's weights: last read in the previous interval)
+    __syncthreads();
+  }
+  ut_tail_store<S>(p, oacc, dcg, b, Y0 + ply - 1, X0 + plx - 1, Hm, Wm);
+}
+
 }  // namespace
 
 extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const float* w0_packed, const float* w3, const float* x_lr, float* out,
@@ -576,7 +740,7 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
   long long grid = (long long)B * p.tiles_y * p.tiles_x;
   if (grid > 0x7fffffffLL) return LFSR_E_ARG;
   const char* usel = lfsr_sel("LFSR_UPTAIL");         // "v1" / "v2": the first / second (fp32-MFMA) forms (A/B runs)
-  if (!(usel && usel[0] == 'v') && !lfsr_arith_f32()) {
+  if (!(usel && usel[0] == 'v') && !lfsr_arith_f32()) {       // (LFSR_UPTAIL=3: handled below)
     const int smem3 = (UT2_ROWS * LDS_ROW + 64 * 9) * 4 + 2 * 3 * 64 * 64 * 2;
     static std::atomic<bool> attr3_set[64];
     if (!attr3_set[dev]) {
@@ -586,6 +750,19 @@ extern "C" int lfsr_up_tail_fwd(const float* f, int f_stride, int f_choff, const
       attr3_set[dev] = true;
     }
     if (((uintptr_t)f | (uintptr_t)w0_packed) & 15) return LFSR_E_ARG;
+    const bool v3 = usel && usel[0] == '3';             // LFSR_UPTAIL=3 (lab): the third form at s = 4 too
+    if (s == 4 && !v3) {
+      const int smem4 = (2 * UT2_ROWS * UR4 + 64 * 9) * 4 + 2 * 3 * 64 * 64 * 2;      // 157952
+      static std::atomic<bool> attr4_set[64];
+      if (!attr4_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_up_tail4), hipFuncAttributeMaxDynamicSharedMemorySize, smem4);
+        if (e != hipSuccess) return LFSR_HIP_ERR(e);
+        attr4_set[dev] = true;
+      }
+      hipLaunchKernelGGL(k_up_tail4, dim3((unsigned)grid), dim3(512), smem4, lfsr_stream(stream), p);
+      LFSR_CHECK_LAUNCH();
+      return LFSR_OK;
+    }
     if (s == 2) hipLaunchKernelGGL((k_up_tail3<2>), dim3((unsigned)grid), dim3(512), smem3, lfsr_stream(stream), p);
     else hipLaunchKernelGGL((k_up_tail3<4>), dim3((unsigned)grid), dim3(512), smem3, lfsr_stream(stream), p);
     LFSR_CHECK_LAUNCH();
