@@ -643,21 +643,33 @@ __global__ __launch_bounds__(512) void k_up_tail4(UpTailArgs p) {
       const int u = wave + 8 * i;
       if (u < 26) {
         const int rt = u >> 1, ch = u & 1;
+        // the unit's two column tiles as two interleaved accumulator chains: consecutive MFMAs never accumulate into the same registers, and one wait covers both (a wave
+        // is alone on its SIMD's matrix pipe in this phase -- its partner is in the gather -- so its own chains are all that fills the pipe: 425 -> 402 us on EPIT's launch;
+        // four chains -- two units interleaved -- measured no further gain)
+        f32x4u acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        asm volatile("s_nop 1" : "+v"(acc0), "+v"(acc1));
+        const unsigned short* wq0 = sWc + (g * 64 + (2 * ch) * 16 + l15) * 8;
+        const unsigned short* wq1 = wq0 + 16 * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const u32x4u a0 = *reinterpret_cast<const u32x4u*>(wq0 + 4 * 64 * 8 * s);
+          const u32x4u a1 = *reinterpret_cast<const u32x4u*>(wq0 + 4 * 64 * 8 * s + WPL);
+          const u32x4u a2 = *reinterpret_cast<const u32x4u*>(wq0 + 4 * 64 * 8 * s + 2 * WPL);
+          const u32x4u b0 = *reinterpret_cast<const u32x4u*>(wq1 + 4 * 64 * 8 * s);
+          const u32x4u b1 = *reinterpret_cast<const u32x4u*>(wq1 + 4 * 64 * 8 * s + WPL);
+          const u32x4u b2 = *reinterpret_cast<const u32x4u*>(wq1 + 4 * 64 * 8 * s + 2 * WPL);
+          ut_mfma(acc0, a2, f0[i][s]); ut_mfma(acc1, b2, f0[i][s]);
+          ut_mfma(acc0, a0, f2[i][s]); ut_mfma(acc1, b0, f2[i][s]);
+          ut_mfma(acc0, a1, f1[i][s]); ut_mfma(acc1, b1, f1[i][s]);
+          ut_mfma(acc0, a1, f0[i][s]); ut_mfma(acc1, b1, f0[i][s]);
+          ut_mfma(acc0, a0, f1[i][s]); ut_mfma(acc1, b0, f1[i][s]);
+          ut_mfma(acc0, a0, f0[i][s]); ut_mfma(acc1, b0, f0[i][s]);
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc0), "+v"(acc1));
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
+          const f32x4u acc = c2 ? acc1 : acc0;
           const int ct = 2 * ch + c2;
-          f32x4u acc = {0.f, 0.f, 0.f, 0.f};
-          asm volatile("s_nop 1" : "+v"(acc));
-          const unsigned short* wq = sWc + (g * 64 + ct * 16 + l15) * 8;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const u32x4u w0 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s);
-            const u32x4u w1 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s + WPL);
-            const u32x4u w2 = *reinterpret_cast<const u32x4u*>(wq + 4 * 64 * 8 * s + 2 * WPL);
-            ut_mfma(acc, w2, f0[i][s]); ut_mfma(acc, w0, f2[i][s]); ut_mfma(acc, w1, f1[i][s]);
-            ut_mfma(acc, w1, f0[i][s]); ut_mfma(acc, w0, f1[i][s]); ut_mfma(acc, w0, f0[i][s]);
-          }
-          asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc));
           float4 o;
           o.x = acc[0] >= 0.f ? acc[0] : acc[0] * p.slope; o.y = acc[1] >= 0.f ? acc[1] : acc[1] * p.slope;
           o.z = acc[2] >= 0.f ? acc[2] : acc[2] * p.slope; o.w = acc[3] >= 0.f ? acc[3] : acc[3] * p.slope;
