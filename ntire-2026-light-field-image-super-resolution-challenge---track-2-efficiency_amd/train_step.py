@@ -41,6 +41,15 @@ def allreduce_bucket(bucket, group=None):
     return bucket
 
 
+def clip_bucket_(bucket, max_norm):
+    """``torch.nn.utils.clip_grad_norm_`` (train.py:266) on the flat bucket every ``.grad`` is a view of: the total 2-norm over all parameters is the norm of the bucket, and the
+    scale is torch's own ``max_norm / (total_norm + 1e-6)`` clamped to 1 -- three launches instead of one norm per parameter plus the foreach scaling (~25 launches at 137
+    tensors); no host synchronisation."""
+    total = torch.linalg.vector_norm(bucket)
+    bucket.mul_((max_norm / (total + 1e-6)).clamp(max=1.0))
+    return total
+
+
 def bind_grads_to_bucket(net):
     """Make every parameter's .grad a view of net.grad_bucket (state_dict order) so the collective and the optimizer
     see the same memory."""
@@ -56,7 +65,7 @@ def train_step(net, criterion, optimizer, x, label, group=None, max_norm=1.0, da
     loss.backward()                             # train.py:264 -> HIP backward fills net.grad_bucket
     allreduce_bucket(net.grad_bucket, group)
     bind_grads_to_bucket(net)
-    torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=max_norm)   # train.py:266
+    clip_bucket_(net.grad_bucket, max_norm)     # train.py:266 (clip_grad_norm_ over all parameters = the norm of the flat bucket they are views of)
     optimizer.step()
     return loss.detach(), out.detach()
 
