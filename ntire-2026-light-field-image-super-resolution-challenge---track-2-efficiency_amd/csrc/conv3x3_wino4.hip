@@ -17,6 +17,7 @@
 //    through a register ring of 16-B fragments (L2 hits, 1 KB contiguous per wave instruction);
 //  * the waves are specialised (see the kernel): four consume (MFMA), four produce (patch loads, input transform, epilogue I/O).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "lfsr_internal.h"
 
@@ -100,6 +101,7 @@ struct Wino4Args {
   const float* R2; int r2_stride; int r2_choff;
   const float* Mk; int mk_stride; int mk_choff; float mk_slope;
   int n_img, H, W, tiles_y, tiles_x, ntiles;
+  int full_per_block, nhalf;   // nhalf > 0: every block walks full_per_block whole tiles, then the nhalf tiles left over are run as 2 nhalf HALF tiles by blocks 0 .. 2 nhalf - 1
   float slope;
 };
 
@@ -123,6 +125,10 @@ __device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, int voff, f32x
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, W4_STPOL);
 }
 
+// Transform position (xi, nu) -> its place p in V's rows, in the U pack and in the accumulators: nu-half major (nu < 3 | nu >= 3), so that the 18 positions a wave of a
+// HALF tile owns are contiguous: fragments (4 positions) 0..3 and the first two values of fragment 4 | the last two of fragment 4 and fragments 5..8.
+#define WP(xi, nu) (18 * ((nu) / 3) + 3 * (xi) + (nu) % 3)
+
 // one 6-vector of the input transform: t = Bt d  (12 operations, integer coefficients: exact products)
 __device__ __forceinline__ void bt6(float& d0, float& d1, float& d2, float& d3, float& d4, float& d5) {
   const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
@@ -137,7 +143,7 @@ __device__ __forceinline__ void at6(f32x4& m0, f32x4& m1, f32x4& m2, f32x4& m3, 
   m0 = (m0 + s12) + s34;
   m1 = d12 + 2.f * d34;
   m2 = s12 + 4.f * s34;
-  m3 = (d12 + 8.f * d34) + m5;
+  m3 = d12 + __builtin_elementwise_fma(f32x4{8.f, 8.f, 8.f, 8.f}, d34, m5);   // (this association -- not (d12 + 8 d34) + m5 -- is the one a tile split between two waves by nu < 3 | nu >= 3 can form: see the half tile)
 }
 
 // HAS_E / HAS_L: the first (residual R1, or the saved activation of the LeakyReLU' mask) / second epilogue operand exists.
@@ -177,7 +183,22 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
   const int nblk = gridDim.x;
   // a block walks a CONTIGUOUS range of tiles (the next tile's patch rows share pages and two pixel rows with this one's)
   int tile = (int)(((long long)blockIdx.x * p.ntiles) / nblk);
-  const int tile_end = (int)(((long long)(blockIdx.x + 1) * p.ntiles) / nblk);
+  int tile_end = (int)(((long long)(blockIdx.x + 1) * p.ntiles) / nblk);
+  // HALF tile (the launch's last, partial round: see the launcher): tile htile for the output channels 32 hc .. 32 hc + 31 only.  Its four consumer waves split the 36
+  // transform positions by nu < 3 | nu >= 3 (wave = (16-channel block, nu half)): half the MFMAs per wave, the partial inverse transforms summed through the exchange planes
+  // in the association at6 uses -- every bit as in a whole tile.
+  bool have_half = false;
+  int htile = 0, hc = 0;
+  if (p.nhalf > 0) {
+    tile = (int)blockIdx.x * p.full_per_block; tile_end = tile + p.full_per_block;
+    have_half = (int)blockIdx.x < 2 * p.nhalf;
+    htile = p.full_per_block * nblk + ((int)blockIdx.x >> 1); hc = (int)blockIdx.x & 1;
+    if ((p.nhalf & 7) == 0 && (nblk & 7) == 0) {   // the two halves of a tile on blocks b and b + 8: the same XCD (workgroups go round-robin over the eight), so the second reader of the tile's halo hits its L2
+      const int b = (int)blockIdx.x;
+      htile = p.full_per_block * nblk + (b >> 4) * 8 + (b & 7); hc = (b >> 3) & 1;
+    }
+  }
+  const bool only_half = tile >= tile_end;     // (block-uniform; such a block always has a half tile)
 #ifdef LFSR_CONV_DIAG
   const int wave = threadIdx.x >> 6;
   unsigned seg[64] = {};
@@ -242,6 +263,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     // ---- input transform of one (Winograd tile, channel) item: R[3 r + k] = patch (row r, columns 2 k, 2 k + 1)
     const float* const hR = sH + ((4 * pty) * 34 + 4 * ptx) * 16 + c16;
     f32x2 R[18];
+    float Vo[36];      // the item's 36 transformed values in position order (scalar results: their registers are the compiler's choice, the order costs nothing)
     auto read_raw = [&]() {
 #pragma unroll
       for (int r = 0; r < 6; ++r)
@@ -264,14 +286,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       for (int r = 0; r < 6; ++r) {
         float d0 = R[3 * r].x, d1 = R[3 * r].y, d2 = R[3 * r + 1].x, d3 = R[3 * r + 1].y, d4 = R[3 * r + 2].x, d5 = R[3 * r + 2].y;
         bt6(d0, d1, d2, d3, d4, d5);
-        R[3 * r].x = d0; R[3 * r].y = d1; R[3 * r + 1].x = d2; R[3 * r + 1].y = d3; R[3 * r + 2].x = d4; R[3 * r + 2].y = d5;
+        Vo[WP(r, 0)] = d0; Vo[WP(r, 1)] = d1; Vo[WP(r, 2)] = d2; Vo[WP(r, 3)] = d3; Vo[WP(r, 4)] = d4; Vo[WP(r, 5)] = d5;
       }
     };
     float* const vW = sV + ptile * TS + c16 * 36;
     auto write_v = [&](int par) {
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        f32x4 v; v.x = R[2 * q].x; v.y = R[2 * q].y; v.z = R[2 * q + 1].x; v.w = R[2 * q + 1].y;
+        f32x4 v; v.x = Vo[4 * q]; v.y = Vo[4 * q + 1]; v.z = Vo[4 * q + 2]; v.w = Vo[4 * q + 3];
         *reinterpret_cast<f32x4*>(vW + par * VBUF + 4 * q) = v;
       }
     };
@@ -315,7 +337,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         if (HAS_E) e[i] = bload4s(rsE, (W4_ABL & 1024) ? (offe & 0xffff) : bad ? OOB : offe, 0);   // (1024: epilogue operand from the image's first 64 KB)
       }
     };
-    auto drain_plane = [&](int a) {
+    auto drain_plane = [&](int a, const int (&py)[4]) {
       const int rowoff = (prow0 + a) * p.W + pcol0;
       f32x4 v[4];
 #pragma unroll
@@ -342,13 +364,17 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
           else { const int offl = pL[i] + rowoff * (l_stride * 4); v[i] += bload4s(rsLp, oy[i] == OOB ? OOB : offl, 0); }
         }
         if (!(W4_ABL & 32) || i == 0) {
-          if (ALIGNED) bstore4(rsYp, (W4_ABL & 256) ? (pY[i] & 0xffff) : pY[i], v[i], (W4_ABL & 256) ? 0 : soY);
+          if (ALIGNED) bstore4(rsYp, (W4_ABL & 256) ? (py[i] & 0xffff) : py[i], v[i], (W4_ABL & 256) ? 0 : soY);
           else bstore4(rsYp, (W4_ABL & 256) ? (oy[i] & 0xffff) : oy[i], v[i]);   // (256: every store into the image's first 64 KB)
         }
       }
     };
 
     int img, y0, x0;
+    bool cur_half = only_half;
+    if (only_half) tile = htile;
+    int himg = 0, hy0 = 0, hx0 = 0;
+    if (have_half) tile_origin(htile, himg, hy0, hx0);
     tile_origin(tile, img, y0, x0);
     __amdgpu_buffer_rsrc_t rsXc = img_rsrc(p.X, p.x_stride, img), rsXn = rsXc;
     halo_offsets(y0, x0);
@@ -363,10 +389,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     LDS_BARRIER();   // (B0)
     while (true) {
       const int next = tile + 1;
-      const bool has_next = next < tile_end;
+      const bool next_full = !cur_half && next < tile_end;
+      const bool next_half = !cur_half && !next_full && have_half;
+      const bool has_next = next_full || next_half;
       // the next tile's origin by stepping (tiles are walked in order: no integer divisions -- ~100 VALU instructions -- per tile)
       int nimg = img, ny0 = y0, nx0 = x0 + 32;
       if (nx0 >= p.W) { nx0 = 0; ny0 += 8; if (ny0 >= p.H) { ny0 = 0; nimg += 1; } }
+      if (next_half) { nimg = himg; ny0 = hy0; nx0 = hx0; }
       if (!has_next) nimg = -1;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -376,7 +405,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         if (!W4_EPF) drain_request(c, prow0, pcol0, rsEp);
         __builtin_amdgcn_sched_barrier(0);
         if (W4_DRAIN) {
-          drain_plane(c);
+          drain_plane(c, pY);
           __builtin_amdgcn_sched_barrier(0);
           if (W4_EPF) {   // plane c + 1; behind plane 3 comes plane 0 of THIS tile (its epilogue operand does not depend on the conv's result)
             if (c < 3) drain_request(c + 1, prow0, pcol0, rsEp);
@@ -398,7 +427,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         if (!(W4_ABL & 4)) write_v((c + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(32 + 8 * c + 3);
-        if (!W4_DRAIN) drain_plane(c);
+        if (!W4_DRAIN) drain_plane(c, pY);
         __builtin_amdgcn_sched_barrier(0);
         if (!(W4_ABL & 1)) halo_load(hv, c == 0 ? rsXc : rsXn, (c + 3) & 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -406,16 +435,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
         if (!(W4_XB && c == 3)) LDS_BARRIER();   // (B)
         PSTAMP(32 + 8 * c + 5);
       }
+      if (cur_half) LDS_BARRIER();   // (half tile: the nu < 3 waves' partial results are in the exchange planes; the nu >= 3 waves add theirs)
       LDS_BARRIER();   // this tile's results are in the exchange planes (W4_XB: and the next tile's first V chunk is published)
       PSTAMP(62);
       rsYp = img_rsrc(p.Y, p.y_stride, img); rsEp = img_rsrc(Ep, e_stride, img); rsLp = img_rsrc(Lp, l_stride, img);
       prow0 = y0; pcol0 = x0;
       if (!has_next) {
+        // a half tile is always a block's last: only this drain has to leave the other 32 channels' units alone (their stores -- and, ragged geometries, their second
+        // operand's loads -- get an out-of-range offset)
+        const bool skip = cur_half && (un >> 3) != hc;
+        int pYf[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { if (!(W4_DRAIN && W4_EPF) || a > 0) drain_request(a, prow0, pcol0, rsEp); drain_plane(a); }
+        for (int i = 0; i < 4; ++i) pYf[i] = skip ? OOB : pY[i];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (!(W4_DRAIN && W4_EPF) || a > 0) drain_request(a, prow0, pcol0, rsEp);
+          if (!ALIGNED && skip) { oy[0] = OOB; oy[1] = OOB; oy[2] = OOB; oy[3] = OOB; }
+          drain_plane(a, pYf);
+        }
         break;
       }
-      tile = next; img = nimg; y0 = ny0; x0 = nx0;
+      tile = next_full ? next : htile; cur_half = next_half; img = nimg; y0 = ny0; x0 = nx0;
       rsXc = rsXn;
     }
   } else {
@@ -426,16 +466,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     const float* const vR = sV + ctile * TS + kk * 36;     // fragment base (parity 0, stage 0): + s4 * 144 + 4 q
     const int uoff = ns * 9216 + lane * 16;                // byte offset of this lane's U fragments within a stage (q = 0)
     const int xw = (cty * 32 + 4 * ctx) * 64 + (((4 * ns + kk) ^ ctx) << 2);   // exchange: pixel (row cty, col 4 ctx + b), 16-B unit XOR ctx
+    // half tile: wave = (16-channel block ob of the half's two, nu half hv); its U / V fragments are 4 hv .. 4 hv + 4 of every stage (five of the nine)
+    const int ob = w4 & 1, hv = w4 >> 1, nsh = 2 * hc + ob;
+    const int uoffh = nsh * 9216 + hv * 4096 + lane * 16;
+    static_assert(W4_URING == 12, "the hand-over of the U ring from a whole tile to the half tile assumes a ring of 12");
     f32x4 U[W4_URING];
 #pragma unroll
-    for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, uoff, ((i / 9) * 36 + (i % 9)) * 1024);
+    for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, only_half ? uoffh : uoff, only_half ? ((i / 5) * 36 + (i % 5)) * 1024 : ((i / 9) * 36 + (i % 9)) * 1024);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[36];
     LDS_BARRIER();   // (A of the prologue)
     LDS_BARRIER();   // (B0)
     STAMP(9);
+    if (!only_half)
     while (true) {
       const bool has_next = tile + 1 < tile_end;
+      const bool to_half = !has_next && have_half;        // the ring's wrap-around loads fetch the half tile's first fragments instead of the next whole tile's
+      const int uoffn = to_half ? uoffh : uoff;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int par = c & 1;
@@ -457,7 +504,8 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
             acc[4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[4 * q + 2], 0, 0, 0);
             acc[4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[4 * q + 3], 0, 0, 0);
             const int tn = (t + W4_URING) % 144;     // (wraps into the next tile: same weights)
-            if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024);
+            if (t + W4_URING < 144) { if (!(W4_ABL & 16)) U[t % W4_URING] = bload4(rsW, uoff, ((tn / 9) * 36 + (tn % 9)) * 1024); }
+            else U[t % W4_URING] = bload4(rsW, uoffn, to_half ? ((tn / 5) * 36 + (tn % 5)) * 1024 : ((tn / 9) * 36 + (tn % 9)) * 1024);
             __builtin_amdgcn_sched_barrier(0);       // (keeps every LDS read two groups ahead of its use)
             if (g == W4_AG) { if (W4_STAMP_A) STAMP(24 + c); if (W4_ANW) BARRIER_NOWAIT(); else LDS_BARRIER(); if (W4_STAMP_A) STAMP(28 + c); }   // (A: the producers have staged the next chunk's halo; they arrive within a group or two)
           }
@@ -468,14 +516,14 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       }
       // At M A in registers; one output row a of every Winograd tile per round -> exchange buffer
 #pragma unroll
-      for (int nu = 0; nu < 6; ++nu) at6(acc[nu], acc[6 + nu], acc[12 + nu], acc[18 + nu], acc[24 + nu], acc[30 + nu]);
+      for (int nu = 0; nu < 6; ++nu) at6(acc[WP(0, nu)], acc[WP(1, nu)], acc[WP(2, nu)], acc[WP(3, nu)], acc[WP(4, nu)], acc[WP(5, nu)]);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         float* const xb = sX + a * 4096;
-        at6(acc[6 * a], acc[6 * a + 1], acc[6 * a + 2], acc[6 * a + 3], acc[6 * a + 4], acc[6 * a + 5]);
+        at6(acc[WP(a, 0)], acc[WP(a, 1)], acc[WP(a, 2)], acc[WP(a, 3)], acc[WP(a, 4)], acc[WP(a, 5)]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          f32x4 v = acc[6 * a + b];
+          f32x4 v = acc[WP(a, b)];
           *reinterpret_cast<f32x4*>(xb + xw + b * 64) = v;
         }
       }
@@ -484,6 +532,88 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
       STAMP(20);
       if (!has_next) break;
       tile += 1;
+    }
+    if (have_half) {
+      // ============================================ the half tile: 18 positions x 16 channels x 16 Winograd tiles per wave ============================================
+      // accumulator j = place - 18 hv = 3 xi + nu % 3.  hv = 0: fragments 0..3 whole (j = 4 ql + e), fragment 4's first two values (j = 16, 17);
+      // hv = 1: fragment 4's last two values (j = 0, 1), fragments 5..8 whole (j = 2 + 4 (ql - 1) + e)
+      const float* const vRh = vR + 16 * hv;
+      auto half_mfmas = [&](auto HV) {
+        constexpr int hvc = decltype(HV)::value;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int par = c & 1;
+          f32x4 Vq[W4_VRING];
+#pragma unroll
+          for (int i = 0; i < W4_VRING - 1; ++i) Vq[i] = *reinterpret_cast<const f32x4*>(vRh + par * VBUF + (i / 5) * 144 + (i % 5) * 4);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+            for (int ql = 0; ql < 5; ++ql) {
+              const int t = (c * 4 + s4) * 5 + ql;     // fragment of the half tile, 0..79
+              const int g = s4 * 5 + ql;               // ... of the chunk
+              constexpr int VA = W4_VRING - 1;
+              if (g + VA < 20) Vq[(g + VA) % W4_VRING] = *reinterpret_cast<const f32x4*>(vRh + par * VBUF + ((g + VA) / 5) * 144 + ((g + VA) % 5) * 4);
+              const f32x4 u = U[t % W4_URING], v = Vq[g % W4_VRING];
+              const bool first = (c == 0 && s4 == 0);
+              if (hvc == 0 ? ql < 4 : ql > 0) {
+                const int j0 = hvc == 0 ? 4 * ql : 4 * ql - 2;
+                acc[j0 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v.x, first ? zero4 : acc[j0 + 0], 0, 0, 0);
+                acc[j0 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v.y, first ? zero4 : acc[j0 + 1], 0, 0, 0);
+                acc[j0 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[j0 + 2], 0, 0, 0);
+                acc[j0 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[j0 + 3], 0, 0, 0);
+              } else if (hvc == 0) {
+                acc[16] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, v.x, first ? zero4 : acc[16], 0, 0, 0);
+                acc[17] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, v.y, first ? zero4 : acc[17], 0, 0, 0);
+              } else {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, v.z, first ? zero4 : acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, v.w, first ? zero4 : acc[1], 0, 0, 0);
+              }
+              const int tn = t + W4_URING;
+              if (tn < 80) U[t % W4_URING] = bload4(rsW, uoffh, ((tn / 5) * 36 + (tn % 5)) * 1024);
+              __builtin_amdgcn_sched_barrier(0);
+              if (g == 12) BARRIER_NOWAIT();           // (A)
+            }
+          }
+          if (c < 3) LDS_BARRIER();                    // (B)
+        }
+        // first pass of At M A (over xi) for the wave's three nu: T[a][n] -> acc[3 a + n]
+#pragma unroll
+        for (int n = 0; n < 3; ++n) at6(acc[n], acc[3 + n], acc[6 + n], acc[9 + n], acc[12 + n], acc[15 + n]);
+        // second pass: this nu half's share of at6's four sums -- (T0 + s12) | s34,  d12 | 2 d34,  s12 | 4 s34,  d12 | fma(8, d34, T5) -- so that "share 0 + share 1"
+        // is at6's own association (2 d34 and 4 s34 are exact, so adding them is what at6's fma does)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const f32x4 t0 = acc[3 * a], t1 = acc[3 * a + 1], t2 = acc[3 * a + 2];
+          if (hvc == 0) {
+            const f32x4 s12 = t1 + t2, d12 = t1 - t2;
+            acc[3 * a] = t0 + s12; acc[3 * a + 1] = d12; acc[3 * a + 2] = s12; acc[12 + a] = d12;
+          } else {
+            const f32x4 s34 = t0 + t1, d34 = t0 - t1;
+            acc[3 * a] = s34; acc[3 * a + 1] = 2.f * d34; acc[3 * a + 2] = 4.f * s34; acc[12 + a] = __builtin_elementwise_fma(f32x4{8.f, 8.f, 8.f, 8.f}, d34, t2);
+          }
+        }
+      };
+      if (hv == 0) half_mfmas(std::integral_constant<int, 0>{}); else half_mfmas(std::integral_constant<int, 1>{});
+      // shares: b = 0..2 in acc[3 a + b], b = 3 in acc[12 + a]
+      const int xwh = (cty * 32 + 4 * ctx) * 64 + (((4 * nsh + kk) ^ ctx) << 2);
+      if (hv == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(sX + a * 4096 + xwh + b * 64) = b < 3 ? acc[3 * a + b] : acc[12 + a];
+      }
+      LDS_BARRIER();
+      if (hv == 1) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            float* const q = sX + a * 4096 + xwh + b * 64;
+            *reinterpret_cast<f32x4*>(q) = *reinterpret_cast<const f32x4*>(q) + (b < 3 ? acc[3 * a + b] : acc[12 + a]);
+          }
+      }
+      LDS_BARRIER();   // the half tile's results are in the exchange planes
     }
   }
 #if W4_CLK
@@ -500,7 +630,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
 #endif
 }
 
-// U = G g G^t per (n, k) -> [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4]
+// U = G g G^t per (n, k) -> [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4], p = WP(xi, nu)
 __device__ __forceinline__ void emit_wino4(const double (&g)[3][3], int n, int k, float* __restrict__ out) {
   const double G[6][3] = {{1.0 / 4, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
@@ -515,7 +645,7 @@ __device__ __forceinline__ void emit_wino4(const double (&g)[3][3], int n, int k
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       const double u = tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2];
-      const int pp = a * 6 + b;
+      const int pp = WP(a, b);
       const int ln = kq * 16 + m;
       out[((((s * 4 + nsl) * 9 + (pp >> 2)) * 64 + ln) << 2) + (pp & 3)] = (float)u;
     }
@@ -634,7 +764,13 @@ int lfsr_conv3x3_wino4_launch(const float* x, int x_stride, int x_choff, const f
   if (nt <= 0 || nt > 0x7fffffffLL) return LFSR_E_ARG;
   p.ntiles = (int)nt;
   const int slots = cus[dev];
-  const unsigned grid = (unsigned)(nt < slots ? nt : slots);
+  unsigned grid = (unsigned)(nt < slots ? nt : slots);
+  // A last round that would keep at most half of the CUs busy is run as half tiles on twice as many (3200 tiles on 256 CUs: 12 rounds + 128 tiles -> 12 + 256 halves;
+  // 800: 3 + 64 halves; 100: 200 halves).  Which tiles are split depends on the batch; their bits do not (see the kernel).
+  {
+    const long long fpb = nt / slots, rem = nt % slots;
+    if (rem > 0 && 2 * rem <= slots && !lfsr_sel("LFSR_CONV_NOHALF")) { p.full_per_block = (int)fpb; p.nhalf = (int)rem; grid = (unsigned)(fpb > 0 ? slots : 2 * rem); }
+  }
   if (!mk && !r1 && r2) { p.R1 = r2; p.r1_stride = r2_stride; p.r1_choff = r2_choff; p.r1_bytes = p.r2_bytes; p.R2 = nullptr; p.r2_bytes = 0; }   // a lone residual is the first operand
   const int act = slope == 1.f ? 0 : (slope >= 0.f && slope < 1.f ? 1 : 2);
   const bool aligned = h % 8 == 0 && w % 32 == 0;

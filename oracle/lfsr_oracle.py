@@ -630,8 +630,10 @@ def winograd4_weights(w):
 
 def winograd4_pack(w):
     """the device layout of the F(4x4,3x3) part of lfsr_pack_conv_weight for a (64, 64, 3, 3) weight:
-    [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4], p = 6 xi + nu (fp64 compute, one rounding to fp32)"""
-    U = winograd4_weights(w.astype(np.float64)).reshape(9, 4, 4, 16, 16, 4)   # q, e, ns, m, s, kq
+    [s = k/4][ns = n/16][q = p/4][lane = 16 (k%4) + n%16][e = p%4], p = 18 (nu // 3) + 3 xi + nu % 3 -- nu-half major, the order in which the
+    kernel keeps the 36 transform positions (a half tile's wave owns 18 contiguous ones) (fp64 compute, one rounding to fp32)"""
+    order = [6 * xi + 3 * hf + n for hf in range(2) for xi in range(6) for n in range(3)]        # natural index 6 xi + nu of place p
+    U = winograd4_weights(w.astype(np.float64)).reshape(36, 64, 64)[order].reshape(9, 4, 4, 16, 16, 4)   # q, e, ns, m, s, kq
     return np.ascontiguousarray(U.transpose(4, 2, 0, 5, 3, 1)).astype(np.float32).reshape(-1)
 
 
