@@ -397,6 +397,17 @@ int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st) {
   return LFSR_E_ARG;
 }
 
+// ... with a second residual operand (dx = conv^T(dy) + r1 + r2, no mask): the group skip of DistgSSR's backward rides on the data gradient of the group's first block
+// instead of a separate read-modify-write pass over dx.  LFSR_E_ARG = not covered (the caller adds r2 itself).
+int lfsr_conv3x3_bwd_data_r2(const float* dy, int dy_stride, const float* wT_packed, float* dx, const float* r1, const float* r2, int n_img, int h, int w, hipStream_t st) {
+  if ((dy_stride & 3) || !r1 || !r2) return LFSR_E_ARG;
+  const char* sel = lfsr_conv3_dgrad_sel();
+  if (sel) return LFSR_E_ARG;      // (lab selections of another 3x3 form: the plain path)
+  LfsrOpTimer op_t("conv3x3_dgrad", n_img, h * w, st);
+  return lfsr_conv3x3_wino4_launch(dy, dy_stride, 0, wT_packed + LFSR_CONV3_DIRECT_FLOATS + LFSR_CONV3_WINO2_FLOATS, dx, 64, 0, r1, 64, 0, r2, 64, 0, nullptr, 0, 0, 1.0f,
+                                   n_img, h, w, 1.0f, st);
+}
+
 int lfsr_conv3x3_bwd_data(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, float* dx, int dx_stride, int dx_choff,
                           const float* r1, int r1_stride, int r1_choff, const float* mk, int mk_stride, int mk_choff, float mk_slope,
                           int n_img, int h, int w, hipStream_t st) {

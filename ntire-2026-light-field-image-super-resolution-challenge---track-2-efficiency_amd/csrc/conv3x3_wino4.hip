@@ -15,7 +15,11 @@
 //    8-lane groups of ds_write_b128 are both conflict-free;
 //  * U never touches LDS: the pack is in fragment order [stage k/4][ns][p/4][lane][p%4], a wave streams its 9 KB per stage
 //    through a register ring of 16-B fragments (L2 hits, 1 KB contiguous per wave instruction);
-//  * the waves are specialised (see the kernel): four consume (MFMA), four produce (patch loads, input transform, epilogue I/O).
+//  * the waves are specialised (see the kernel): four consume (MFMA), four produce (patch loads, input transform, epilogue I/O);
+//  * a last round that would fill at most half of the CUs runs as HALF tiles on twice as many (round 4): a CU takes 32 of the tile's output channels, its four
+//    consumer waves split the 36 positions by nu < 3 | nu >= 3 (18 accumulators, five of the nine U / V fragments per stage each) and the two partial inverse
+//    transforms meet in the exchange planes, added in the association at6 itself uses -- so which tiles are split (a function of the batch) changes no bit.
+//    800 tiles on 256 CUs: 3 rounds + 64 half tiles instead of 4 rounds (58.4 -> 54.2 us per op on one box, 50.2 on a faster one); 100 tiles: 16.6 -> 12.9 us.
 #include <stdlib.h>
 #include <type_traits>
 
@@ -42,6 +46,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define W4_AG 24      // the MFMA group (0..35) of a chunk at which the consumers join barrier A (producers: halo staged); 8..30 measured the same (profiles/r04_logs)
 #endif
 
+#ifndef W4_HAG
+#define W4_HAG 12     // ... and of a half tile's chunk (0..19)
+#endif
 #ifndef W4_DRAIN
 #define W4_DRAIN 1    // 1: the producers drain the previous tile's exchange plane BEFORE barrier A (while they would wait for the consumers to get there) instead of
                       // behind the V writes, where its four LDS round trips sat on the path that the consumers wait for at the chunk barrier
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
               const int tn = t + W4_URING;
               if (tn < 80) U[t % W4_URING] = bload4(rsW, uoffh, ((tn / 5) * 36 + (tn % 5)) * 1024);
               __builtin_amdgcn_sched_barrier(0);
-              if (g == 12) BARRIER_NOWAIT();           // (A)
+              if (g == W4_HAG) BARRIER_NOWAIT();       // (A)
             }
           }
           if (c < 3) LDS_BARRIER();                    // (B)

@@ -576,6 +576,7 @@ static int distgssr_backward_impl(lfsr_distgssr* c, const float* x, const float*
   // ---- groups, reversed ----------------------------------------------------------------------------------------
   for (int g = c->G - 1; g >= 0; --g) {
     float* dG = gcur;   // gradient at the group's output; also flows through the group skip to its input
+    bool skip_fused = false;
     const float* blk_last = t.OUT[g * c->NB + c->NB - 1];
     std::string gk = "disentg.Group." + std::to_string(g) + ".conv.weight";
     RC(wgrad3(gk, blk_last, dG, 64));
@@ -612,7 +613,12 @@ static int distgssr_backward_impl(lfsr_distgssr* c, const float* x, const float*
       RC(wgrad3(p + "SpaConv.2.weight", t.S1[i], t.dCAT, 144));
       RC(dgrad3(t.dCAT, 144, p + "SpaConv.2.weight", t.dS1, nullptr, nullptr, t.S1[i], 64));
       RC(wgrad3(p + "SpaConv.0.weight", Xin, t.dS1, 64));
-      RC(dgrad3(t.dS1, 64, p + "SpaConv.0.weight", gx, gy, nullptr, nullptr, 0));          // gx = gy (block skip) + dSpa
+      // gx = gy (block skip) + dSpa; in the group's first block the group skip dG rides along as the second residual (else: one more pass over gx at the group's end)
+      if (b == 0 && !skip_fused) {
+        const int r2rc = lfsr_conv3x3_bwd_data_r2(t.dS1, 64, c->wT(p + "SpaConv.0.weight"), gx, gy, dG, nimg, h, w, st);
+        if (r2rc == LFSR_OK) skip_fused = true; else if (r2rc != LFSR_E_ARG) return r2rc;
+      }
+      if (!(b == 0 && skip_fused)) RC(dgrad3(t.dS1, 64, p + "SpaConv.0.weight", gx, gy, nullptr, nullptr, 0));
       // AngConv : CAT[64:80] = PS(lrelu(1x1(A16))), A16 = lrelu(convAxA(Xin))          (branch_bwd.cpp; also exported as lfsr_angconv_bwd)
       // EPIConv (horizontal, then vertical; shared weights -> both partial sets summed in one reduce)                 (lfsr_epiconv_hv_bwd)
       const float *wa0 = c->w(p + "AngConv.0.weight"), *wa0T = c->wT(p + "AngConv.0.weight"), *wa2T = c->wT(p + "AngConv.2.weight");
@@ -641,7 +647,7 @@ static int distgssr_backward_impl(lfsr_distgssr* c, const float* x, const float*
       gy = gx;
     }
     // group skip: grad at the group's input = (through the blocks) + dG
-    RC(lfsr_add_inplace(gy, dG, (long long)npix * 64, st));
+    if (!skip_fused) RC(lfsr_add_inplace(gy, dG, (long long)npix * 64, st));
     gcur = gy;
   }
   // ---- init_conv: F0 = conv(x) ; dF0 = (through the groups) + dD (cascade skip) -------------------------------

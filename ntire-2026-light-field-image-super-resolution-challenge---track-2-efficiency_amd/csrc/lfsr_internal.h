@@ -139,6 +139,7 @@ struct LfsrGemm {
   int M, N, A, h, w, ntaps, CH;
 };
 int lfsr_bwd_gemm(const LfsrGemm& g, hipStream_t st);
+int lfsr_conv3x3_bwd_data_r2(const float* dy, int dy_stride, const float* wT_packed, float* dx, const float* r1, const float* r2, int n_img, int h, int w, hipStream_t st);
 int lfsr_conv3x3_bwd_data(const float* dy, int dy_stride, int dy_choff, const float* wT_packed, float* dx, int dx_stride, int dx_choff,
                           const float* r1, int r1_stride, int r1_choff, const float* mk, int mk_stride, int mk_choff, float mk_slope,
                           int n_img, int h, int w, hipStream_t st);

@@ -141,6 +141,34 @@ def test_conv3x3_bench_size_properties(monkeypatch):
     assert float((lin - ref).abs().max()) < 2e-5 * float(ref.abs().max())     # (F(4x4,3x3): ~1e-5 relative)
 
 
+@pytest.mark.parametrize("h,w", [(32, 32), (30, 29)])
+def test_conv3x3_half_tiles_change_no_bit(h, w):
+    """The launch's last partial round runs as HALF tiles when it would fill at most half of the CUs (conv3x3_wino4.hip: two CUs per tile, the 36 transform positions
+    split between waves, partial inverse transforms summed through LDS).  Which tiles are split depends on the image count only: on 256 CUs, 100 images (400 tiles) run
+    whole, 72 images (288 tiles) run images 64..71 as halves, 25 images (100 tiles) run every tile as halves -- an image's result must not change by a bit
+    (forward with activation, two-residual form, data gradient with the LeakyReLU' mask and a residual; aligned and ragged geometry)."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    n = 100
+    x = torch.randn(n * h * w, 64, device="cuda", generator=g)
+    r = torch.randn(n * h * w, 64, device="cuda", generator=g)
+    act = torch.randn(n * h * w, 64, device="cuda", generator=g)
+    wt = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    wp, wtp = capi.pack_conv_weight(wt), capi.pack_conv_weight_T(wt)
+    forms = [lambda k: capi.conv3x3(x[:k * h * w], wp, k, h, w, slope=0.1),
+             lambda k: capi.conv3x3(x[:k * h * w], wp, k, h, w, slope=1.0, res1=r[:k * h * w], res2=r[:k * h * w]),
+             lambda k: capi.conv3x3_dgrad(x[:k * h * w], wtp, k, h, w, res1=r[:k * h * w], act=act[:k * h * w], act_slope=0.1)]
+    for f in forms:
+        whole = f(100).clone()
+        for k in (72, 25):
+            part = f(k)
+            assert torch.equal(part, whole[:k * h * w]), (k, h, w)
+    # ... and the half-tile launch against the fp64 oracle
+    xs = x[:25 * h * w].reshape(25, h, w, 64).permute(0, 3, 1, 2).cpu().numpy().astype(np.float64)
+    ref = O.leaky_relu(O.conv2d(xs, wt.cpu().numpy().astype(np.float64), padding=(1, 1)), 0.1)
+    y = capi.conv3x3(x[:25 * h * w], wp, 25, h, w, slope=0.1).reshape(25, h, w, 64).permute(0, 3, 1, 2).cpu().numpy()
+    assert np.abs(y - ref).max() < ATOL
+
+
 @pytest.mark.parametrize("B,A,h,w", GEOMS)
 def test_angconv(B, A, h, w):
     x = rnd((B, 64, A * h, A * w), 4)
