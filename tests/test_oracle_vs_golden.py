@@ -187,12 +187,15 @@ def test_winograd4_restatement_equals_direct_conv():
     assert np.abs(O.conv3x3_winograd4(x, w) - ref).max() < 1e-11
     y32 = O.conv3x3_winograd4(x.astype(np.float32), w.astype(np.float32))
     assert np.abs(y32 - ref).max() < 2e-4          # fp32 round-off of F(4x4,3x3) on unit-variance data (|y| ~ 8)
-    # packed layout: entry (s, ns, q, lane, e) holds U[p = 4 q + e][n = 16 ns + lane % 16][k = 4 s + lane / 16]
+    # packed layout: entry (s, ns, q, lane, e) holds U of place p = 4 q + e for [n = 16 ns + lane % 16][k = 4 s + lane / 16]; place p = 18 (nu // 3) + 3 xi + nu % 3
+    # (nu-half major: the 18 positions a half tile's wave owns are contiguous)
     w64 = rng.standard_normal((64, 64, 3, 3)).astype(np.float32)
     pk = O.winograd4_pack(w64).reshape(16, 4, 9, 64, 4)
-    U = O.winograd4_weights(w64.astype(np.float64)).reshape(36, 64, 64)
-    for (s_, ns, q, ln, e) in [(0, 0, 0, 0, 0), (15, 3, 8, 63, 3), (3, 1, 5, 37, 2), (9, 2, 7, 16, 1)]:
-        assert pk[s_, ns, q, ln, e] == np.float32(U[4 * q + e, 16 * ns + ln % 16, 4 * s_ + ln // 16])
+    U = O.winograd4_weights(w64.astype(np.float64))          # [xi][nu][n][k]
+    for (s_, ns, q, ln, e) in [(0, 0, 0, 0, 0), (15, 3, 8, 63, 3), (3, 1, 5, 37, 2), (9, 2, 7, 16, 1), (2, 0, 4, 5, 1), (2, 0, 4, 5, 2)]:
+        pl = 4 * q + e
+        hf, xi, n3 = pl // 18, (pl % 18) // 3, pl % 3
+        assert pk[s_, ns, q, ln, e] == np.float32(U[xi, 3 * hf + n3, 16 * ns + ln % 16, 4 * s_ + ln // 16])
 
 
 def test_winograd4_roundoff_through_the_whole_network():
