@@ -15,7 +15,7 @@ python3 - <<'P'
 import csv, glob, collections, json, os
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 out = {}
-for tag, keys in (("infer", ("k_epi_b3", "k_conv3x3_wino4<false, false", "k_conv3x3_wino4<false, true", "k_rowgemm_b3", "k_ang_fused", "k_epi_wino5")), ("lft", ("k_win_attn_mfma", "k_ffn_b3", "k_rowgemm_b3", "k_up_tail3"))):
+for tag, keys in (("infer", ("k_epi_b3", "k_conv3x3_wino4<false, false", "k_conv3x3_wino4<false, true", "k_rowgemm_b3", "k_ang_fused", "k_epi_wino5")), ("lft", ("k_win_attn_mfma", "k_ffn_b3", "k_rowgemm_b3", "k_up_tail4"))):
     for f in sorted(glob.glob(f"{R}/gpurun_out/r4/pmc/{tag}_*/**/*counter_collection.csv", recursive=True)):
         acc = collections.defaultdict(lambda: collections.defaultdict(float))
         for r in csv.DictReader(open(f)):
