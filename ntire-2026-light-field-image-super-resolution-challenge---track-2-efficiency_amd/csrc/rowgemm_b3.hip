@@ -15,6 +15,9 @@
 #ifndef RB_VAR
 #define RB_VAR 1   // timing variants (correct results): 1 residual rows loaded in the epilogue (default: out-projection at the LFT geometry 274 us against 291 us with the loads at the top of the tile)
 #endif
+#ifndef RB_EARLY
+#define RB_EARLY 1   // 1: the next tile's rows requested in front of this tile's split (two raw-row sets); 0: behind it (one set)
+#endif
 #ifndef RB_ABL
 #define RB_ABL 0   // diagnostic timing builds (WRONG results; tools/build_abl.sh): 1 no LayerNorm / split VALU, 2 no MFMAs, 4 no stores (and no residual loads), 8 no row loads after the first
 #endif
@@ -98,10 +101,13 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
   typedef float f32x4g __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)(p.M * p.x_stride * 4), 0x00020000);
   const int offL = ((wave * 16 + l15) * p.x_stride + p.x_choff + 8 * g) * 4;
-  float4 xr[KS][2];
+  // RB_EARLY (plain row-GEMMs): two sets of raw rows -- the next tile's rows are asked for BEFORE this tile's split (into the other set) instead of behind it, so a tile's
+  // loads have the split, the MFMAs and the epilogue of the previous tile to arrive in
+  constexpr bool EARLY = RB_EARLY && !LN;
+  float4 xrA[KS][2], xrB[EARLY ? KS : 1][2];
   float4 pr[LN ? KS : 1][2];
   const bool do_ln = LN && n0 < p.ln_cols;
-  auto prefetch = [&](long long tile) {
+  auto prefetch = [&](long long tile, float4 (&xr)[KS][2]) {
     // (the tile's base goes into the VGPR offset: the descriptor's bounds check covers the VGPR and immediate offsets only, an SGPR offset is added unchecked)
     const int ot = offL + (int)(tile * BMR) * p.x_stride * 4;
 #pragma unroll
@@ -137,12 +143,12 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
     offR[t] = ok && p.R1 ? (unsigned)(((wave * 16 + l15) * p.r1_stride + p.r1_choff + n) * 4) : OOB;
   }
   long long tile = blockIdx.x;
-  prefetch(tile < ntiles ? tile : ntiles);
+  prefetch(tile < ntiles ? tile : ntiles, xrA);
 #pragma unroll
   for (int t = 0; t < NT; ++t)      // NT dropped stores: the first tile meets the loop head in the same counter state as every other one
     __builtin_amdgcn_raw_buffer_store_b128(u32x4b{0u, 0u, 0u, 0u}, rsY, OOB, 0, 0);
   const unsigned short* wl = swb + (g * NB + l15) * 8;         // this lane's A-operand slot: k-group g, weight row l15 (+16 rows per sub-tile, + 4 NB slots per K step)
-  for (; tile < ntiles; tile += gridDim.x) {
+  auto body = [&](float4 (&xr)[KS][2], float4 (&xn)[KS][2]) {
     // the residual rows of THIS tile, asked for before the arithmetic (older than the next prefetch: the epilogue waits for them alone)
     const int so = (int)(tile * BMR);
     f32x4g rv[NT];
@@ -154,6 +160,10 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
         for (int t = 0; t < NT; ++t) rv[t] = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rsR, offR[t] + (unsigned)(so * p.r1_stride * 4), 0, 0));
     };
     if (!(RB_VAR & 1)) load_res();
+    if constexpr (EARLY) {
+      if (!(RB_ABL & 8)) prefetch(tile + gridDim.x < ntiles ? tile + gridDim.x : ntiles, xn);
+      __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks these loads in between the split's instructions: the point is that they are in flight before it)
+    }
     if constexpr (LN) if (do_ln && !(RB_ABL & 1)) {
       // nn.LayerNorm(K) of the lane's row: its K values sit in the four lanes (row l15, g = 0..3), 8 KS each -- an in-lane sum and two wave shuffles per pass
       float sm = 0.f;
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
         x2[s] = x0[s];
       } else b3_split8(xr[s][0], xr[s][1], x0[s], x1[s], x2[s]);
     }
-    if (!(RB_ABL & 8)) prefetch(tile + gridDim.x < ntiles ? tile + gridDim.x : ntiles);      // (past the end: rows >= M, zeros without traffic)
+    if constexpr (!EARLY) if (!(RB_ABL & 8)) prefetch(tile + gridDim.x < ntiles ? tile + gridDim.x : ntiles, xn);      // (past the end: rows >= M, zeros without traffic; !EARLY: xn is xr)
     f32x4b acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4b{0.f, 0.f, 0.f, 0.f};
@@ -244,6 +254,16 @@ __global__ __launch_bounds__(NB * 4) void k_rowgemm_b3(RowGemmB3Args p) {
         __builtin_amdgcn_raw_buffer_store_b128(u32x4b{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsY, offY[t] + (unsigned)(so * ys * 4), 0, 0);
       }
     }
+  };
+  if constexpr (EARLY) {
+    for (;;) {
+      if (tile >= ntiles) break;
+      body(xrA, xrB); tile += gridDim.x;
+      if (tile >= ntiles) break;
+      body(xrB, xrA); tile += gridDim.x;
+    }
+  } else {
+    for (; tile < ntiles; tile += gridDim.x) body(xrA, xrA);
   }
 }
 
