@@ -2,7 +2,8 @@
 """A/B timing of builds of the 3x3 conv kernel inside ONE process, variants interleaved round-robin (device-to-device and clock-ramp
 spread makes figures of different processes incomparable).
 usage: python tools/conv_ab.py tag=lib.so [tag=lib.so ...]      (the first one is the reference for the bit comparison)
-env: AB_ROUNDS (default 6), AB_REPS (default 20), AB_GEOMS (default "800:n,800:y,200:n")"""
+env: AB_ROUNDS (default 6), AB_REPS (default 20), AB_GEOMS (default "800:n,800:y,200:n"), AB_NW (default 1): that many different packed weights used in turn
+(16 x 590 KB do not fit an XCD's L2: every launch then streams its U fragments cold, as the convs of a forward do)"""
 import ctypes as C, os, sys, statistics
 import torch
 
@@ -33,15 +34,20 @@ def main():
     wt = torch.randn(64, 64, 3, 3, device="cuda", generator=gen) * 0.05
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     packs = {}
+    nw = int(os.environ.get("AB_NW", "1"))
     for t, lib in libs:
         n = lib.lfsr_packed_weight_floats(64, 64, 9)
-        wp = torch.empty(n, device="cuda")
-        assert lib.lfsr_pack_conv_weight(wt.data_ptr(), wp.data_ptr(), 64, 64, 9, 0, 0, st) == 0
-        packs[t] = wp
+        packs[t] = []
+        for _ in range(nw):
+            wp = torch.empty(n, device="cuda")
+            assert lib.lfsr_pack_conv_weight(wt.data_ptr(), wp.data_ptr(), 64, 64, 9, 0, 0, st) == 0
+            packs[t].append(wp)
+    cnt = [0]
     y = torch.empty(nmax * h * w, 64, device="cuda")
 
     def run(lib, t, n_img, res):
-        rc = lib.lfsr_conv3x3_fwd(x.data_ptr(), 64, 0, packs[t].data_ptr(), y.data_ptr(), 64, 0, r.data_ptr() if res else None, 64 if res else 0, 0,
+        cnt[0] += 1
+        rc = lib.lfsr_conv3x3_fwd(x.data_ptr(), 64, 0, packs[t][cnt[0] % nw].data_ptr(), y.data_ptr(), 64, 0, r.data_ptr() if res else None, 64 if res else 0, 0,
                                   None, 0, 0, n_img, h, w, 0.1, st)
         assert rc == 0, rc
 
