@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_wino4(Wino4Args p) {
     // half tile: wave = (16-channel block ob of the half's two, nu half hv); its U / V fragments are 4 hv .. 4 hv + 4 of every stage (five of the nine)
     const int ob = w4 & 1, hv = w4 >> 1, nsh = 2 * hc + ob;
     const int uoffh = nsh * 9216 + hv * 4096 + lane * 16;
-    static_assert(W4_URING == 12, "the hand-over of the U ring from a whole tile to the half tile assumes a ring of 12");
+    static_assert(144 % W4_URING == 0, "the ring position of a whole tile's last fragments (and so of the half tile's first, handed over by the wrap-around loads) must be 0");
     f32x4 U[W4_URING];
 #pragma unroll
     for (int i = 0; i < W4_URING; ++i) U[i] = bload4(rsW, only_half ? uoffh : uoff, only_half ? ((i / 5) * 36 + (i % 5)) * 1024 : ((i / 9) * 36 + (i % 9)) * 1024);
