@@ -17,6 +17,10 @@
 
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 
+#ifndef WA_XCD_RANGES
+#define WA_XCD_RANGES 1   // 1: an XCD's units cover a contiguous range of (sequence, strip) pairs; 0: pairs dealt round-robin over the XCDs
+#endif
+
 namespace {
 
 constexpr int WA_ROWS = 12, WA_KP = 40, WA_VD = 484;                    // staged key rows, key-row pitch (keys), V^T pitch per d (floats)
@@ -33,6 +37,8 @@ struct WinAttnArgs {
   unsigned nheads;
   long long nunits;  // sequences x strips x heads
   int remap;         // 1: the XCD-aware unit order (needs (sequences x strips) and the grid to be multiples of 8)
+  int t_per_xcd;     // (sequences x strips) / 8: an XCD walks a CONTIGUOUS range of (sequence, strip) pairs -- vertically adjacent strips share four of their twelve key rows,
+                     // and with the strips dealt round-robin over the XCDs (round 3) no L2 ever saw both: 1.19 x the algorithmic bytes per launch, all of it that halo
   int nstrip, ntc; // strips of 8 query rows per sequence; 4-column query tiles per row
   float scale;     // 1 / sqrt(16) * log2(e)
 };
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void k_win_attn_mfma(WinAttnArgs p) {
     if (p.remap) {
       const unsigned xcd = u & 7, jx = u >> 3;
       U.head = (int)(jx % p.nheads);
-      t = (jx / p.nheads) * 8 + xcd;
+      t = WA_XCD_RANGES ? xcd * (unsigned)p.t_per_xcd + jx / p.nheads : (jx / p.nheads) * 8 + xcd;
     } else {
       U.head = (int)(u % p.nheads);
       t = u / p.nheads;
@@ -267,6 +273,7 @@ int lfsr_win_attn_mfma_launch(const float* q, int q_stride, int q_choff, const f
   long long grid = 2LL * cus[dev];                          // two 60-KB blocks per CU
   if (grid > p.nunits) grid = p.nunits;
   p.remap = (nblk % 8 == 0 && grid % 8 == 0) ? 1 : 0;
+  p.t_per_xcd = (int)(nblk / 8);
   hipLaunchKernelGGL(k_win_attn_mfma, dim3((unsigned)grid), dim3(256), WA_SMEM, st, p);
   LFSR_CHECK_LAUNCH();
   return LFSR_OK;
